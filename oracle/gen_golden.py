@@ -1,0 +1,397 @@
+#!/usr/bin/env python3
+"""gen_golden.py - makes tests/golden/ from the REAL reference.  TEST INFRASTRUCTURE.
+
+Run in the build container only (needs /root/reference and oracle/_ref/libredref.so, built by
+``make -C oracle ref``).  Everything written is DATA: serialized DFA blobs the reference's own
+compiler produced, input byte strings, and the outputs the reference's matcher returned for
+them - plus the expected values the reference's own gtest files assert, transcribed as data.
+No reference source text is stored.
+
+Outputs (all under tests/golden/):
+  dfas/<name>.reda            blobs of the BASELINE config DFAs (reference compiler output)
+  kat_matcher.json            known answers asserted by test/matcher.cpp, test/executable.cpp,
+                              test/serializer.cpp, test/fnv.cpp (+ the blobs, per format)
+  omnibus.json(+.npz)         the 160-row {regex,text,shouldMatch} table of
+                              test/omnibus.cpp:244-407, with per-format blobs
+  vectors_<name>.npz          reference outputs for every verb x style x doLeader on a mixed
+                              set of crafted + random inputs, per config DFA
+"""
+from __future__ import annotations
+
+import base64
+import json
+import os
+import re
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+import oracle as O  # noqa: E402
+from one_amd import workloads as W  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+REFTEST = "/root/reference/quol/red/test"
+FORMATS = [("auto", O.FMT_AUTO), ("1", O.FMT_1), ("2", O.FMT_2), ("4", O.FMT_4)]
+STY = ["instant", "first", "tangent", "last", "full"]
+
+
+def b64(b: bytes) -> str:
+    return base64.b64encode(b).decode()
+
+
+def compile_all_formats(patterns):
+    out = {}
+    for name, fmt in FORMATS:
+        try:
+            out[name] = O.ref_compile(patterns, fmt)
+        except O.RefError as e:
+            out[name] = ("limit" if e.code == -3 else "parse" if e.code == -4 else "err", str(e))
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# Known answers asserted by the reference's own tests (values transcribed from the EXPECT_*
+# lines; the generator re-runs each through the reference and refuses to write on mismatch).
+# call = (verb, style, doLeader, input, expected) ; expected = result | (result,start,end)
+# with None = "not asserted by the reference test".  Run-time-style overloads use
+# doLeader=true (lib/Matcher.cpp:53-62).
+# ------------------------------------------------------------------------------------------
+IC, LS = O.F_IGNORE_CASE, O.F_LOOSE_START
+RAW, AUTO = O.LANG_RAW, O.LANG_AUTO
+NUM3 = [("[0-9]+", 1, 0), ("[0-9]+a", 2, 0), ("[0-9]+abcd", 3, 0)]
+
+
+def _verify(style, rows):
+    calls = []
+    for text, exp in rows:
+        calls += [("check", style, True, text, exp[0]), ("match", style, True, text, exp),
+                  ("search", style, True, text, exp)]
+    return calls
+
+
+def _searchrows(style, rows):
+    calls = []
+    for text, exp in rows:
+        calls += [("scan", style, True, text, exp[0]), ("search", style, True, text, exp)]
+    return calls
+
+
+KAT = [
+    dict(name="case", src="test/matcher.cpp:22-42", patterns=[("abc", 1, 0)],
+         calls=[("check", "full", False, "abc", 1), ("check", "full", False, "aBc", 0),
+                ("check", "full", False, "ABC", 0), ("check", "full", False, "xyz", 0)]),
+    dict(name="case_ignore", src="test/matcher.cpp:22-42", patterns=[("abc", 1, IC)],
+         calls=[("check", "full", False, "abc", 1), ("check", "full", False, "aBc", 1),
+                ("check", "full", False, "ABC", 1), ("check", "full", False, "xyz", 0)]),
+    dict(name="endmarks", src="test/matcher.cpp:45-58", patterns=[("abe", 1, 0), ("ace", 2, 0)],
+         calls=[("check", "full", False, "abe", 1), ("check", "full", False, "ace", 2),
+                ("check", "full", False, "abc", 0), ("check", "full", False, "age", 0)]),
+    dict(name="start_degenerate", src="test/matcher.cpp:61-77", patterns=[("a*", 1, 0)],
+         calls=[("search", "last", True, "123a", (1, 3, 4)),
+                ("search", "last", True, "123az", (1, 4, 4))]),
+    dict(name="start_intended", src="test/matcher.cpp:79-93", patterns=[(".*[a-z]+", 1, 0)],
+         calls=[("search", "last", True, "123a", (1, 3, 4)),
+                ("search", "last", True, "123az!", (1, 3, 5))]),
+    dict(name="startEnd", src="test/matcher.cpp:97-125",
+         patterns=[("[^a]*ab*c", 1, 0), ("[^d]*dummy", 2, 0)],
+         calls=[("match", "last", True, "abbc", (1, 0, 4)),
+                ("match", "last", True, "xabbc", (1, 1, 5)),
+                ("match", "last", True, "xabbcx", (1, 1, 5)),
+                ("match", "last", True, "xyzabbcxyz", (1, 3, 7))]),
+    dict(name="matchTangent", src="test/matcher.cpp:129-146", patterns=[("[0-9]+", 1, 0)],
+         calls=[("match", "instant", True, "0123456789abcdef", (1, None, 1)),
+                ("match", "first", True, "0123456789abcdef", (1, None, 10)),
+                ("match", "tangent", True, "0123456789abcdef", (1, None, 10))]),
+    dict(name="matchLast", src="test/matcher.cpp:149-163",
+         patterns=[("New", 1, LS), ("New York", 2, LS), ("York", 3, LS)],
+         calls=[("match", "last", True, "I love New York.", (2, 7, 15))]),
+    dict(name="verifyInstant", src="test/matcher.cpp:166-213", patterns=NUM3,
+         calls=_verify("instant", [("1", (1, 0, 1)), ("123", (1, 0, 1)), ("123abcd", (1, 0, 1)),
+                                   ("123abcde", (1, 0, 1))])),
+    dict(name="verifyFirst", src="test/matcher.cpp:216-263", patterns=NUM3,
+         calls=_verify("first", [("1", (1, 0, 1)), ("123", (1, 0, 3)), ("123abcd", (1, 0, 3)),
+                                 ("123XYZ", (1, 0, 3))])),
+    dict(name="verifyTangent", src="test/matcher.cpp:266-313", patterns=NUM3,
+         calls=_verify("tangent", [("1", (1, 0, 1)), ("123", (1, 0, 3)), ("123abcd", (2, 0, 4)),
+                                   ("123XYZ", (1, 0, 3))])),
+    dict(name="verifyLast", src="test/matcher.cpp:316-363", patterns=NUM3,
+         calls=_verify("last", [("1", (1, 0, 1)), ("123", (1, 0, 3)), ("123abcd", (3, 0, 7)),
+                                ("123abcde", (3, 0, 7))])),
+    dict(name="verifyFull", src="test/matcher.cpp:366-413", patterns=NUM3,
+         calls=_verify("full", [("1", (1, 0, 1)), ("123", (1, 0, 3)), ("123abcd", (3, 0, 7)),
+                                ("123abcde", (0, 0, 0))])),
+    dict(name="searchInstant", src="test/matcher.cpp:417-460", patterns=NUM3,
+         calls=_searchrows("instant", [(".,_1", (1, 3, 4)), (".,_123", (1, 3, 4)),
+                                       (".,_123abcd", (1, 3, 4)), (".,_123abcde", (1, 3, 4))])),
+    dict(name="searchFirst", src="test/matcher.cpp:463-506", patterns=NUM3,
+         calls=_searchrows("first", [(".,_1", (1, 3, 4)), (".,_123", (1, 3, 6)),
+                                     (".,_123abcd", (1, 3, 6)), (".,_123XYZ", (1, 3, 6))])),
+    dict(name="searchTangent", src="test/matcher.cpp:509-552", patterns=NUM3,
+         calls=_searchrows("tangent", [(".,_1", (1, 3, 4)), (".,_123", (1, 3, 6)),
+                                       (".,_123abcd", (2, 3, 7)), (".,_123XYZ", (1, 3, 6))])),
+    dict(name="searchLast", src="test/matcher.cpp:555-598", patterns=NUM3,
+         calls=_searchrows("last", [(".,_1", (1, 3, 4)), (".,_123", (1, 3, 6)),
+                                    (".,_123abcd", (3, 3, 10)), (".,_123abcde", (3, 3, 10))])),
+    dict(name="searchFull", src="test/matcher.cpp:601-644", patterns=NUM3,
+         calls=_searchrows("full", [(".,_1", (1, 3, 4)), (".,_123", (1, 3, 6)),
+                                    (".,_123abcd", (3, 3, 10)), (".,_123abcde", (0, 0, 0))])),
+    dict(name="check_overloads", src="test/matcher.cpp:753-772; test/executable.cpp:69-81",
+         patterns=[("ab*c", 1, 0, AUTO), ("ca*b", 2, 0, AUTO)],
+         calls=[("check", "full", True, "bca", 0), ("check", "full", True, "bac", 1),
+                ("check", "full", True, "cab", 2),
+                ("match", "full", True, "bca", (0, None, 0)),
+                ("match", "full", True, "bac", (1, None, 3)),
+                ("match", "full", True, "cab", (2, None, 3))]),
+    dict(name="exec_memory", src="test/executable.cpp:26-64; test/serializer.cpp:29-53",
+         patterns=[("ab*c", 1, 0, AUTO)],
+         calls=[("match", "full", True, "abbc", (1, None, None))]),
+    # SURVEY.md section 8(a) a-M / a-N quirks, verified there against the reference
+    dict(name="quirk_start_after_end", src="SURVEY.md a-M quirk 1", patterns=[(".*error", 1, 0)],
+         calls=[("match", "last", False, "an error: foo e", (1, 14, 8)),
+                ("match", "tangent", False, "an error: foo e", (1, 3, 8))]),
+    dict(name="quirk_accepting_initial", src="SURVEY.md a-M quirk 2", patterns=[("a*", 1, 0)],
+         calls=[("match", "last", False, "", (1, 0, 0)), ("match", "last", False, "b", (0, 0, 0)),
+                ("match", "instant", False, "b", (0, 0, 0))]),
+    dict(name="quirk_accepting_deadend", src="SURVEY.md a-M quirk 3", patterns=[("abc.*", 1, 0)],
+         calls=[("match", "last", False, "abcdefgh", (1, 0, 8)),
+                ("match", "full", False, "abcdefgh", (1, 0, 8))]),
+    dict(name="quirk_scan_leader_skip", src="SURVEY.md a-N quirk", patterns=[("aab", 1, 0)],
+         calls=[("scan", "instant", True, "aaab", 0), ("scan", "instant", False, "aaab", 1),
+                ("search", "instant", True, "aaab", (1, 1, 4))]),
+]
+
+FNV64_KAT = dict(src="test/fnv.cpp:11-21", text=b64(b"chongo was here!\n"),
+                 answers=[[0, "cbf29ce484222325"], [1, "af63de4c8601eff2"],
+                          [2, "08a25607b54a22ae"], [17, "46810940eff5f915"],
+                          [6, "e150688c8217b8fd"]])
+
+
+def run_call(ref, verb, style, lead, text: bytes):
+    if verb in ("check", "scan"):
+        return getattr(ref, verb)(text, style, lead)
+    return getattr(ref, verb)(text, style, lead)
+
+
+def agrees(got, exp) -> bool:
+    if isinstance(exp, int):
+        return got == exp
+    return all(e is None or g == e for g, e in zip(got, exp))
+
+
+def gen_kat():
+    cases = []
+    for k in KAT:
+        blobs = compile_all_formats(k["patterns"])
+        case = dict(name=k["name"], src=k["src"], blobs={}, calls=[])
+        for fname, blob in blobs.items():
+            if isinstance(blob, tuple):
+                case["blobs"][fname] = {"error": blob[0]}
+                continue
+            case["blobs"][fname] = {"reda": b64(blob)}
+            ref, cpu = O.Reference(blob), O.CpuOracle(blob)
+            for verb, style, lead, text, exp in k["calls"]:
+                tb = text.encode("latin-1")
+                got = run_call(ref, verb, style, lead, tb)
+                assert agrees(got, exp), (k["name"], fname, verb, style, text, got, exp)
+                got2 = run_call(cpu, verb, style, lead, tb)
+                assert got == got2, ("oracle!=ref", k["name"], fname, verb, style, text)
+        for verb, style, lead, text, exp in k["calls"]:
+            case["calls"].append(dict(verb=verb, style=style, lead=lead,
+                                      text=b64(text.encode("latin-1")),
+                                      expect=exp if isinstance(exp, int) else list(exp)))
+        cases.append(case)
+    zero = dict(src="test/serializer.cpp:20-24", size=1024, expect_bad=True)
+    assert O.ref_check_header(b"\0" * 1024) is not None
+    with open(os.path.join(GOLD, "kat_matcher.json"), "w") as f:
+        json.dump(dict(cases=cases, zero_header=zero, fnv64=FNV64_KAT), f, indent=0)
+    print("kat_matcher.json:", len(cases), "cases")
+
+
+# ------------------------------------------------------------------------------------------
+_REC = re.compile(r'Rec\{')
+
+
+def c_unescape(s: str) -> bytes:
+    out = bytearray()
+    i = 0
+    simple = {"n": 10, "t": 9, "r": 13, "\\": 92, '"': 34, "'": 39, "0": 0, "a": 7, "b": 8,
+              "f": 12, "v": 11, "?": 63}
+    while i < len(s):
+        c = s[i]
+        if c != "\\":
+            out += c.encode("latin-1")
+            i += 1
+            continue
+        i += 1
+        c = s[i]
+        if c == "x":
+            j = i + 1
+            while j < len(s) and s[j] in "0123456789abcdefABCDEF":
+                j += 1
+            out.append(int(s[i + 1:j], 16) & 0xFF)
+            i = j
+        elif c in "01234567":
+            j = i
+            while j < len(s) and j < i + 3 and s[j] in "01234567":
+                j += 1
+            out.append(int(s[i:j], 8) & 0xFF)
+            i = j
+        else:
+            out.append(simple[c])
+            i += 1
+    return bytes(out)
+
+
+def parse_omnibus_rows():
+    """Reads the {regex,text,shouldMatch} DATA rows of test/omnibus.cpp (testRecs[])."""
+    src = open(os.path.join(REFTEST, "omnibus.cpp"), encoding="latin-1").read()
+    beg = src.index("Rec testRecs[] = {")
+    end = src.index("};", beg)
+    body = src[beg:end]
+    rows = []
+    tok = re.compile(r'"((?:[^"\\]|\\.)*)"|\b(nullptr|true|false)\b|(Rec\{)|(\})|(,)')
+    cur = None
+    for m in tok.finditer(body[body.index("{") + 1:]):
+        if m.group(3):
+            cur = []
+            sep = False
+        elif m.group(4):
+            if cur is not None:
+                rows.append(cur)
+                cur = None
+        elif cur is not None:
+            if m.group(5):
+                sep = True
+            elif m.group(1) is not None:
+                # adjacent string literals (no comma between) concatenate
+                if cur and isinstance(cur[-1], list) and not sep:
+                    cur[-1].append(m.group(1))
+                else:
+                    cur.append([m.group(1)])
+                sep = False
+            else:
+                cur.append(m.group(2))
+                sep = False
+    out = []
+    for r in rows:
+        regex = c_unescape("".join(r[0]))
+        text = None if r[1] == "nullptr" else c_unescape("".join(r[1]))
+        out.append((regex, text, r[2] == "true"))
+    return out
+
+
+def gen_omnibus():
+    rows = parse_omnibus_rows()
+    assert len(rows) == 160, len(rows)  # 160 Rec{} rows in testRecs[]
+    blobs = {}
+    meta = []
+    for i, (regex, text, should) in enumerate(rows):
+        rec = dict(regex=b64(regex), text=None if text is None else b64(text), match=should,
+                   fmt={})
+        for fname, fmt in FORMATS:
+            try:
+                blob = O.ref_compile([(regex, 1, 0, O.LANG_AUTO)], fmt)
+            except O.RefError as e:
+                kind = {-3: "limit", -4: "parse"}.get(e.code, "err")
+                rec["fmt"][fname] = kind
+                if kind == "parse":
+                    assert text is None, (i, regex)
+                continue
+            assert text is not None, (i, regex)
+            ref, cpu = O.Reference(blob), O.CpuOracle(blob)
+            # the test calls check(rex, const char*, styFull): C-string input, doLeader=true
+            t = text.split(b"\0")[0]
+            r1 = ref.check(t, "full", True)
+            r2 = ref.match(t, "full", True)
+            assert r1 == r2[0] and (r1 == 1) == should, (i, regex, t, r1, r2)
+            assert cpu.check(t, "full", True) == r1 and cpu.match(t, "full", True) == r2
+            key = "r%03d_%s" % (i, fname)
+            blobs[key] = np.frombuffer(blob, dtype=np.uint8)
+            rec["fmt"][fname] = key
+        meta.append(rec)
+    with open(os.path.join(GOLD, "omnibus.json"), "w") as f:
+        json.dump(dict(src="test/omnibus.cpp:244-407,506-555", rows=meta), f, indent=0)
+    np.savez_compressed(os.path.join(GOLD, "omnibus_blobs.npz"), **blobs)
+    print("omnibus:", len(meta), "rows,", len(blobs), "blobs")
+
+
+# ------------------------------------------------------------------------------------------
+def config_dfas():
+    d = {}
+    d["err"] = O.ref_compile([("error", 1, 0)])
+    d["uri"] = O.ref_compile([(W.URI_REGEX, 1, O.F_LOOSE_START)])
+    d["log100"] = O.ref_compile(W.log100_patterns())
+    d["syn256"] = O.ref_syn_dfa(256, 42)
+    d["num3"] = O.ref_compile(NUM3)
+    d["newyork"] = O.ref_compile([("New", 1, LS), ("New York", 2, LS), ("York", 3, LS)])
+    d["aab"] = O.ref_compile([("aab", 1, 0)])
+    d["dotstar_err"] = O.ref_compile([(".*error", 1, 0)])
+    return d
+
+
+def inputs_for(name: str, rng: np.random.Generator):
+    """A mixed bag of crafted and random inputs (list of bytes)."""
+    ins = [b"", b"a", b"e", b"error", b"erro", b"errorx", b"xerror", b"an error: foo e",
+           b"aaab", b"aab", b"aabaab", b"123abcd", b".,_123abcde", b"I love New York.",
+           b"New", b"New York", b"York", b"0", b"0123456789abcdef", b"\0\0", b"\xff" * 5]
+    heads = W.log100_heads()
+    ins += heads[:10] + [h[:-3] for h in heads[10:20]] + [b"x" + h for h in heads[20:24]]
+    ins += [W.URI_PLANT, b"see " + W.URI_PLANT, b"http://1.2.3.4", b"ftp://a.bc/",
+            b"http://a.b", b"xxhttps://a.io:80/?#", b"HTTP://A.COM"]
+    for _ in range(700):
+        n = int(rng.integers(0, 200))
+        ins.append(W.ALPHABET47[rng.integers(0, 47, n)].tobytes())
+    for _ in range(300):
+        n = int(rng.integers(0, 300))
+        ins.append(rng.integers(0, 256, n, dtype=np.uint8).tobytes())
+    for _ in range(300):  # planted positives at random places in noise
+        pre = W.ALPHABET47[rng.integers(0, 47, int(rng.integers(0, 40)))].tobytes()
+        post = W.ALPHABET47[rng.integers(0, 47, int(rng.integers(0, 40)))].tobytes()
+        mid = [b"error", W.URI_PLANT, heads[int(rng.integers(0, 100))], b"New York",
+               b"%d" % rng.integers(0, 10**6), b"123abcd", b"aab"][int(rng.integers(0, 7))]
+        ins.append(pre + mid + post)
+    return ins
+
+
+def gen_vectors():
+    dfas = config_dfas()
+    for name, blob in dfas.items():
+        with open(os.path.join(GOLD, "dfas", name + ".reda"), "wb") as f:
+            f.write(blob)
+        info = O.CpuOracle(blob).info
+        print("dfa %-12s %8d B  %s" % (name, len(blob), info))
+        rng = np.random.default_rng(0xC0FFEE)
+        ins = inputs_for(name, rng)
+        data = np.frombuffer(b"".join(ins), dtype=np.uint8)
+        offsets = np.zeros(len(ins) + 1, dtype=np.uint64)
+        offsets[1:] = np.cumsum([len(x) for x in ins])
+        ref, cpu = O.Reference(blob), O.CpuOracle(blob)
+        arrays = dict(data=data, offsets=offsets)
+        for verb in ("check", "match", "scan", "search"):
+            for si, sty in enumerate(STY, start=1):
+                for lead in (0, 1):
+                    r, s, e = ref.batch(verb, sty, lead, data, offsets=offsets)
+                    r2, s2, e2 = cpu.batch(verb, sty, lead, data, offsets=offsets)
+                    assert (r == r2).all() and (s == s2).all() and (e == e2).all(), \
+                        ("oracle!=ref", name, verb, sty, lead)
+                    key = "%s_%d_%d" % (verb, si, lead)
+                    arrays[key + "_res"] = r
+                    if verb in ("match", "search"):
+                        arrays[key + "_start"] = s
+                        arrays[key + "_end"] = e
+        np.savez_compressed(os.path.join(GOLD, "vectors_%s.npz" % name), **arrays)
+
+
+def main():
+    os.makedirs(os.path.join(GOLD, "dfas"), exist_ok=True)
+    gen_kat()
+    gen_omnibus()
+    gen_vectors()
+
+
+if __name__ == "__main__":
+    main()

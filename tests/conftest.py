@@ -1,0 +1,20 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_oracle():
+    """The C restatement is test infrastructure: build it on demand (gcc, ~1 s)."""
+    import oracle
+    if not os.path.exists(oracle.LIB_ORACLE):
+        oracle.build(ref=False)

@@ -1,0 +1,88 @@
+"""The CPU restatement (oracle/red_oracle.c) against every golden vector: the known answers the
+reference's own tests assert, and the outputs of the reference itself on the config DFAs."""
+import numpy as np
+import pytest
+
+import oracle as O
+from golden_util import (CONFIG_DFAS, STYLES, expect_of, kat_items, load_dfa, load_kat,
+                         load_omnibus, load_vectors, unb64)
+
+
+def _run(cpu, verb, style, lead, text):
+    return getattr(cpu, verb)(text, style, lead)
+
+
+def test_kat_matcher_cpp():
+    n = 0
+    for name, fmt, blob, calls in kat_items():
+        cpu = O.CpuOracle(blob)
+        for c in calls:
+            got = _run(cpu, c["verb"], c["style"], c["lead"], unb64(c["text"]))
+            exp = c["expect"]
+            if isinstance(exp, int):
+                assert got == exp, (name, fmt, c)
+            else:
+                for g, e in zip(got, exp):
+                    assert e is None or g == e, (name, fmt, c, got)
+            n += 1
+    assert n > 400
+
+
+def test_zero_header_rejected():
+    # test/serializer.cpp:20-24
+    z = load_kat()["zero_header"]
+    assert O.check_header(b"\0" * z["size"]) == "Serialized DFA: bad magic number"
+
+
+def test_header_messages():
+    blob = bytearray(load_dfa("err"))
+    assert O.check_header(bytes(blob)) is None
+    assert O.check_header(bytes(blob[:100])) == "Serialized DFA: header too short"
+    b = bytearray(blob); b[5] = 9
+    assert O.check_header(bytes(b)) == "Serialized DFA: unrecognized version"
+    b = bytearray(blob); b[-1] ^= 1
+    assert O.check_header(bytes(b)) == "serialized DFA: checksum mismatch"
+    b = bytearray(blob); b[8:12] = b[8:12][::-1]
+    assert O.check_header(bytes(b)) == "serialized DFA: foreign endian-ness"
+    with pytest.raises(ValueError):
+        O.CpuOracle(bytes(b))
+
+
+def test_fnv64_kat():
+    # test/fnv.cpp:11-21
+    k = load_kat()["fnv64"]
+    text = unb64(k["text"]) + b"\0"
+    for n, hexval in k["answers"]:
+        assert O.fnv1a64(text[:n]) == int(hexval, 16)
+
+
+def test_omnibus_table():
+    rows, blobs = load_omnibus()
+    assert len(rows) == 160
+    checked = 0
+    for r in rows:
+        for fmt, key in r["fmt"].items():
+            if key in ("limit", "parse", "err"):
+                continue
+            cpu = O.CpuOracle(blobs[key].tobytes())
+            text = unb64(r["text"]).split(b"\0")[0]
+            res = cpu.check(text, "full", True)
+            oc = cpu.match(text, "full", True)
+            assert res == oc[0] and (res == 1) == r["match"], (r, fmt)
+            checked += 1
+    assert checked > 500
+
+
+@pytest.mark.parametrize("name", CONFIG_DFAS)
+def test_reference_vectors(name):
+    vec = load_vectors(name)
+    cpu = O.CpuOracle(load_dfa(name))
+    data, offsets = vec["data"], vec["offsets"]
+    for verb in ("check", "match", "scan", "search"):
+        for si, sty in enumerate(STYLES, start=1):
+            for lead in (0, 1):
+                er, es, ee = expect_of(vec, verb, si, lead)
+                r, s, e = cpu.batch(verb, sty, lead, data, offsets=offsets, threads=2)
+                assert np.array_equal(r, er), (name, verb, sty, lead)
+                if es is not None:
+                    assert np.array_equal(s, es) and np.array_equal(e, ee), (name, verb, sty)

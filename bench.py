@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py - GB/s of input scanned by the MI355X DFA match-execution path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the hot path (match<styLast,false> = "matchLong", full Outcome:
+result + start + end) over one batch of synthetic input already resident in HBM.
+Workload at every N = BASELINE.json configs[1], per GPU: the 256-state / 256-class DFA
+(tests/golden/dfas/syn256.reda, produced by the reference's minimizer + serializer) over
+2^20 lines x 64 B = 64 MiB of uniform random bytes; >= 5 distinct input buffers are rotated so
+that no step finds its input in the 256 MiB Infinity Cache.  N > 1: one process per GPU,
+weak scaling (every rank scans its own shard, no data-path collective); the per-line results
+are gathered to rank 0 over RCCL in compact form, overlapped with the following steps, and the
+last gather completes inside the timed region.
+
+Prints ONE JSON line on rank 0 (see the driver's contract) with `roofline` (dominant kernel
+vs the 8 TB/s HBM peak, timed with events on the launch stream) and `cpu_baseline` (the
+reference's CPU matcher on this box's host cores, rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--lines", type=int, default=1 << 20)
+    ap.add_argument("--line-len", type=int, default=64)
+    ap.add_argument("--dfa", default="syn256", choices=["syn256", "uri"])
+    ap.add_argument("--buffers", type=int, default=6)
+    ap.add_argument("--no-start", action="store_true", help="outputs result + end only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--gather-every", type=int, default=8,
+                    help="N>1: steps per RCCL result gather")
+    return ap.parse_args()
+
+
+def make_inputs(args, rank, torch, W):
+    """Distinct per-rank, per-buffer synthetic batches, generated on the host with the same
+    counter-based generator the tests use, then made resident in HBM."""
+    import numpy as np
+    bufs, hosts = [], []
+    for k in range(args.buffers):
+        seed = 42 + 1000 * rank + k
+        if args.dfa == "syn256":
+            h = W.fixed_lines(args.lines, args.line_len, seed, alphabet=False)
+        else:
+            h = W.fixed_lines(args.lines, args.line_len, seed, plant=W.URI_PLANT)
+        t = torch.from_numpy(h).cuda()
+        bufs.append(t)
+        hosts.append(h if k == 0 else None)
+    return bufs, hosts[0]
+
+
+def cpu_baseline(args, blob, host_batch):
+    """The reference's own CPU matcher (oracle/_ref, compiled from the reference sources) if
+    its prebuilt .so travelled with the repo, else the C restatement; all host cores, one
+    contiguous shard per thread as tools/thr_red.cpp:86-91 does.  Bounded to ~cpu_seconds."""
+    import oracle
+    cores = os.cpu_count() or 1
+    if oracle.have_ref():
+        eng, kind = oracle.Reference(blob), "reference"
+    else:
+        eng, kind = oracle.CpuOracle(blob), "port"
+    n, L = args.lines, args.line_len
+    eng.batch("match", "last", 0, host_batch[: 4096 * L], stride=L, n=4096, threads=cores)
+    t0 = time.perf_counter()
+    passes = 0
+    while True:
+        eng.batch("match", "last", 0, host_batch, stride=L, n=n, threads=cores)
+        passes += 1
+        dt = time.perf_counter() - t0
+        if dt >= args.cpu_seconds or passes >= 200:
+            break
+    gbs = passes * n * L / dt / 1e9
+    # single-thread figure for context
+    t1 = time.perf_counter()
+    m = min(n, 1 << 18)
+    eng.batch("match", "last", 0, host_batch[: m * L], stride=L, n=m, threads=1)
+    one = m * L / (time.perf_counter() - t1) / 1e9
+    return {"value": round(gbs, 3), "unit": "GB/s", "cores": cores, "kind": kind,
+            "sample": "%d passes over the full %d x %d B batch, match<styLast,false>, "
+                      "%d threads" % (passes, n, L, cores),
+            "single_thread_GBps": round(one, 3)}
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import one_amd
+    from one_amd import workloads as W
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    with open(os.path.join(ROOT, "tests", "golden", "dfas", args.dfa + ".reda"), "rb") as f:
+        blob = f.read()
+    exe = one_amd.Executable(blob, device=local_rank)
+    info = exe.info
+    n, L = args.lines, args.line_len
+    want_start = not args.no_start
+
+    bufs, host0 = make_inputs(args, rank, torch, W)
+    nout = 3
+    outs = [(torch.empty(n, dtype=torch.int32, device="cuda"),
+             torch.empty(n, dtype=torch.int64, device="cuda") if want_start else None,
+             torch.empty(n, dtype=torch.int64, device="cuda")) for _ in range(nout)]
+
+    def step(i):
+        return one_amd.match_batch(exe, bufs[i % len(bufs)], one_amd.styLast, False, stride=L,
+                                   n=n, want_start=want_start, out=outs[i % nout])
+
+    # ---- correctness gate: buffer 0 bit-exact against the CPU oracle ------------------------
+    import oracle
+    r, s, e = step(0)
+    torch.cuda.synchronize()
+    er, es, ee = oracle.CpuOracle(blob).batch("match", "last", 0, host0, stride=L, n=n,
+                                              threads=os.cpu_count() or 1)
+    bit_exact = bool(np.array_equal(r.cpu().numpy(), er) and
+                     np.array_equal(e.cpu().numpy().astype(np.uint64), ee) and
+                     (not want_start or np.array_equal(s.cpu().numpy().astype(np.uint64), es)))
+    kernel_name = one_amd.last_kernel()
+
+    # ---- multi-GPU result gather (compact wire form, widened on rank 0) ---------------------
+    gather = None
+    if world > 1:
+        from one_amd import sharding
+        gather = sharding.ResultGather(n, args.gather_every, world, rank, L, info["max_result"],
+                                       want_start)
+
+    for i in range(args.warmup):
+        o = step(i)
+        if gather:
+            gather.push(i, o)
+    if gather:
+        gather.flush()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(args.steps):
+        o = step(i)
+        if gather:
+            gather.push(i, o)
+    ev1.record()
+    if gather:
+        gather.flush()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    region_ms = ev0.elapsed_time(ev1)
+
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- dominant kernel, per launch, with events on the launch stream ----------------------
+    # (separate loop so that the event records do not sit inside the timed region)
+    kms = []
+    for i in range(min(args.steps, 100)):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        step(i)
+        b.record()
+        kms.append((a, b))
+    torch.cuda.synchronize()
+    per_launch = sorted(a.elapsed_time(b) for a, b in kms)
+    k_avg_ms = sum(per_launch) / len(per_launch)
+    k_med_ms = per_launch[len(per_launch) // 2]
+    back_to_back_ms = region_ms / args.steps
+
+    bytes_per_step = n * L
+    out_bytes = n * (4 + 8 + (8 if want_start else 0))
+    value = world * args.steps * bytes_per_step / elapsed / 1e9
+    # roofline: algorithmic input bytes per launch / average duration of the launch.  The
+    # back-to-back figure (events around the whole timed region / K) includes launch gaps and
+    # is the conservative one we report as `achieved`.
+    kernel_ms = back_to_back_ms if world == 1 else k_avg_ms
+    achieved = bytes_per_step / (kernel_ms * 1e-3) / 1e9
+    line = {
+        "metric": "GB/s input scanned (and Minput/s) for fixed DFA",
+        "value": round(value, 2),
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {
+            "workload": "configs[1]: %s DFA (%d states used / %d classes, REDA fmtDirect%d), "
+                        "%d lines x %d B per GPU, match<styLast,false> -> %s" %
+                        (args.dfa, info["states_used"], info["n_classes"], info["format"], n, L,
+                         "result+start+end" if want_start else "result+end"),
+            "lines_per_gpu": n, "line_len": L, "rotating_input_buffers": len(bufs),
+            "sharding": "contiguous shard per GPU, no data-path collective" +
+                        ("; RCCL gather of compact results every %d steps" % args.gather_every
+                         if world > 1 else ""),
+        },
+        "minputs_per_s": round(world * args.steps * n / elapsed / 1e6, 1),
+        "bit_exact": bit_exact,
+        "kernel": kernel_name,
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": bytes_per_step,
+            "output_bytes_per_launch": out_bytes,
+            "kernel_ms_back_to_back": round(back_to_back_ms, 5),
+            "kernel_ms_event_pair_avg": round(k_avg_ms, 5),
+            "kernel_ms_event_pair_median": round(k_med_ms, 5),
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args, blob, host0)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.destroy_process_group()
+    if not bit_exact:
+        raise SystemExit("bench: GPU output differs from the oracle - number is invalid")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,152 @@
+/* redgpu.h - C-ABI of the MI355X-native DFA match-execution path for RED (zezax/one, quol/red).
+ *
+ * This is the drop-in boundary.  RED has no FFI layer of its own: the seam is the C++ value
+ * type `Executable` (a validated serialized-DFA blob, include/Executable.h:28-76) and the free
+ * functions `check / match / scan (const Executable&, const void* ptr, size_t len[, Style])`
+ * (include/Matcher.h:79-98,133-169).  Every entry point below names the reference interface it
+ * replaces; citations are relative to /root/reference/quol/red/.  The reference-side binding a
+ * maintainer would add is shown in INTEGRATION.md; the C++ mirror of the reference's names is
+ * include/redgpu.hpp.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every function returns 0 (REDGPU_OK) or a negative code
+ *     and leaves a message for redgpu_last_error() (thread-local).  The reference signals the
+ *     same conditions with exceptions (include/Except.h:9-19): EAPI <-> RedExceptApi,
+ *     EEXEC <-> RedExceptExec, ELIMIT <-> RedExceptLimit.  "No match" is result 0, not an error.
+ *   - a redgpu_dfa is immutable after creation; all *_batch calls are re-entrant on a shared
+ *     handle from any number of host threads (the reference's threading contract,
+ *     doc/Performance.md:81-84, tools/thr_red.cpp:86-91).
+ *   - inputs: line i is data[offsets[i], offsets[i+1]) when offsets != NULL (n+1 entries),
+ *     else data[i*stride, (i+1)*stride).  Inputs/outputs are caller-owned and never retained.
+ *   - outputs are the fields of the reference's Outcome (include/Outcome.h:32-35):
+ *     result int32, start/end uint64 (size_t).  `start` and `end` may be NULL.
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails
+ *     with REDGPU_EHIP.
+ */
+#ifndef REDGPU_H
+#define REDGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REDGPU_OK      0
+#define REDGPU_EAPI   (-1) /* bad blob / bad arguments      (RedExceptApi)   */
+#define REDGPU_EEXEC  (-2) /* unsupported format / style    (RedExceptExec)  */
+#define REDGPU_ELIMIT (-3) /* capacity exceeded             (RedExceptLimit) */
+#define REDGPU_EHIP   (-5) /* HIP runtime / device failure  (new)            */
+
+/* include/Matcher.h:67-74 */
+#define REDGPU_STY_INSTANT 1
+#define REDGPU_STY_FIRST   2
+#define REDGPU_STY_TANGENT 3
+#define REDGPU_STY_LAST    4
+#define REDGPU_STY_FULL    5
+
+#define REDGPU_DEVICE_CURRENT (-1) /* upload to the calling thread's current HIP device */
+#define REDGPU_DEVICE_NONE    (-2) /* validate + repack on the host only (no HIP call);
+                                      batch calls on such a handle fail with REDGPU_EAPI */
+
+typedef struct redgpu_dfa redgpu_dfa;
+
+typedef struct redgpu_opts {
+  int32_t  device;        /* HIP device ordinal, or REDGPU_DEVICE_CURRENT / _NONE */
+  uint32_t lds_table_max; /* 0 = default; cap (bytes) on the LDS-resident table */
+  uint32_t flags;         /* REDGPU_F_* */
+  uint32_t reserved[5];
+} redgpu_opts;
+
+#define REDGPU_F_FORCE_GENERIC 1u /* never pick the specialised fixed-stride kernels */
+#define REDGPU_F_FORCE_GLOBAL  2u /* keep the transition table in HBM/L2 even if it fits LDS */
+
+/* table placements reported by redgpu_dfa_info */
+#define REDGPU_TAB_LDS_FUSED_U8   1 /* [state][byte] -> next state, u8,  in LDS */
+#define REDGPU_TAB_LDS_FUSED_U16  2 /* [state][byte] -> next state, u16, in LDS */
+#define REDGPU_TAB_LDS_CLASS_U16  3 /* [state][class] u16 + equivalence map, both in LDS */
+#define REDGPU_TAB_GLOBAL_U16     4 /* [state][class] u16 in HBM/L2, equivalence map in LDS */
+#define REDGPU_TAB_GLOBAL_U32     5 /* [state][class] u32 in HBM/L2, equivalence map in LDS */
+
+typedef struct redgpu_info {
+  uint32_t format;        /* 1, 2, 4: FileHeader.format_ (include/Serializer.h:34-40,47) */
+  uint32_t n_classes;     /* maxChar_ + 1 */
+  uint32_t leader_len;
+  uint32_t states_total;  /* FileHeader.stateCnt_ */
+  uint32_t states_used;   /* reachable from the initial state (what the device image holds) */
+  uint32_t n_pure_dead;   /* device states [0, n_pure_dead) are pure dead ends (Proxy.h:139) */
+  uint32_t first_accept;  /* device states [first_accept, states_used) have result > 0 */
+  uint32_t table_kind;    /* REDGPU_TAB_* */
+  uint64_t table_bytes;
+  int32_t  max_result;
+  int32_t  device;
+  uint32_t checksum;      /* FileHeader.checksum_ */
+  uint32_t fast_path;     /* 1 if the fixed-stride specialised kernels apply to this DFA */
+} redgpu_info;
+
+/* Replaces checkHeader (include/Serializer.h:109, lib/Serializer.cpp:270-298): returns
+ * REDGPU_OK, or REDGPU_EAPI with *msg (if msg != NULL) pointing at a static string that is
+ * byte-for-byte the reference's message. */
+int redgpu_reda_check(const void *reda, size_t len, const char **msg);
+
+/* Replaces Executable(gCopyTag, string_view) + Executable::validate
+ * (include/Executable.h:37, lib/Executable.cpp:53-70,159-170): validates exactly as
+ * checkHeader does, additionally bounds-checks every row offset (the GPU must never chase a
+ * corrupt pointer), COPIES the blob, repacks it and uploads the image to opts->device.
+ * opts == NULL means {REDGPU_DEVICE_CURRENT, 0, 0}.  The caller's buffer may be freed or
+ * scrambled immediately (test/red.cpp:55-78). */
+int redgpu_dfa_create(const void *reda, size_t len, const redgpu_opts *opts, redgpu_dfa **out);
+
+/* Replaces ~Executable (lib/Executable.cpp:127-139). */
+void redgpu_dfa_destroy(redgpu_dfa *dfa);
+
+/* Replaces the Executable accessors (include/Executable.h:52-60). */
+int redgpu_dfa_info(const redgpu_dfa *dfa, redgpu_info *out);
+
+/* Replaces Executable::serialized() (include/Executable.h:50): the handle's own copy. */
+int redgpu_dfa_serialized(const redgpu_dfa *dfa, const void **reda, size_t *len);
+
+/* ---- batch verbs over HOST buffers (allocates device staging, copies in and out) ---------
+ * Each replaces the caller's per-input loop (tools/bench.cpp:60-71, tools/thr_red.cpp:36-47)
+ * around one reference function:
+ *   redgpu_check_batch <-> check<style,doLeader>(exec, ptr, len)  include/Matcher.h:133-134,363-410
+ *   redgpu_match_batch <-> match<style,doLeader>(exec, ptr, len)  include/Matcher.h:146-147,413-495
+ *                          (style 4 = styLast is the "matchLong" of BASELINE.json)
+ *   redgpu_scan_batch  <-> scan<style,doLeader>(exec, ptr, len)   include/Matcher.h:159-160,498-554
+ * The run-time-style overloads of the reference (Matcher.h:79-92, Matcher.cpp:53-67) are these
+ * with do_leader = 1. */
+int redgpu_check_batch(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                       const uint64_t *offsets, uint64_t stride, uint64_t n, int32_t *result);
+int redgpu_match_batch(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                       const uint64_t *offsets, uint64_t stride, uint64_t n, int32_t *result,
+                       uint64_t *start, uint64_t *end);
+int redgpu_scan_batch(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                      const uint64_t *offsets, uint64_t stride, uint64_t n, int32_t *result);
+
+/* ---- the same verbs over DEVICE-resident buffers, asynchronous on `stream` ---------------
+ * data/offsets/result/start/end are device pointers on the handle's device; `stream` is a
+ * hipStream_t (NULL = the default stream).  Nothing is allocated, copied or synchronised. */
+int redgpu_check_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                           const uint64_t *offsets, uint64_t stride, uint64_t n,
+                           int32_t *result, void *stream);
+int redgpu_match_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                           const uint64_t *offsets, uint64_t stride, uint64_t n,
+                           int32_t *result, uint64_t *start, uint64_t *end, void *stream);
+int redgpu_scan_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                          const uint64_t *offsets, uint64_t stride, uint64_t n, int32_t *result,
+                          void *stream);
+
+/* Name of the kernel the last *_batch* call on this thread launched (for profiles), or "". */
+const char *redgpu_last_kernel(void);
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char *redgpu_last_error(void);
+
+/* Library version: major*10000 + minor*100 + patch. */
+int redgpu_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REDGPU_H */

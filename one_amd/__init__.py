@@ -1,0 +1,15 @@
+"""one_amd - MI355X-native DFA match execution for RED (zezax/one quol/red).
+
+Only the hot path lives here: `csrc/` (gfx950 HIP kernels + the C-ABI of include/redgpu.h),
+`matcher.py` (host-side mirror of the reference's Executable / Style / check / match / scan),
+`sharding.py` (one process per GPU, contiguous shards, RCCL result gather) and `workloads.py`
+(synthetic inputs of the BASELINE configs).  Importing the package does not load the HIP
+extension; the first call does, and fails loudly if it is not built.
+"""
+from .matcher import (Executable, Style, RedExcept, RedExceptApi, RedExceptExec,  # noqa: F401
+                      RedExceptLimit, RedExceptHip, check, check_batch, check_header, match,
+                      match_batch, scan, scan_batch, last_kernel, styInstant, styFirst,
+                      styTangent, styLast, styFull)
+
+__all__ = ["Executable", "Style", "check", "match", "scan", "check_batch", "match_batch",
+           "scan_batch", "check_header", "last_kernel"]

@@ -1,0 +1,61 @@
+// dfa_image.h - host-side reader of RED's serialized DFA ("REDA") and its repack into the
+// layout the gfx950 kernels walk.  Pure host C++ (no HIP) so it is testable without a GPU.
+//
+// Reference layout being read (citations relative to /root/reference/quol/red/):
+//   FileHeader            include/Serializer.h:42-59   (288 bytes, little-endian, packed)
+//   StateDirect1/2/4 rows include/Serializer.h:62-77, lib/Serializer.cpp:39-53
+//   base / leader / map   lib/Executable.cpp:159-170
+//   header validation     lib/Serializer.cpp:270-306, include/Fnv.h:36-66
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace redgpu {
+
+constexpr size_t kHeaderBytes = 288;
+
+// What lives in HBM/LDS.  States are RENUMBERED: only states reachable from the initial
+// state are kept, ordered so that the two per-byte predicates of the reference's loops become
+// integer compares on the state index instead of a second table lookup:
+//     s <  nPureDead    <=>  DfaProxy::pureDeadEnd()   (include/Proxy.h:139-141)
+//     s >= firstAccept  <=>  DfaProxy::result() > 0    (include/Proxy.h:131-133)
+struct DfaImage {
+  // from the header
+  uint32_t format = 0;       // 1 / 2 / 4
+  uint32_t nClasses = 0;     // maxChar_ + 1
+  uint32_t leaderLen = 0;
+  uint32_t statesTotal = 0;  // stateCnt_
+  uint32_t checksum = 0;
+  uint8_t  equiv[256] = {};  // byte -> class
+  uint8_t  leader[256] = {}; // class-space fixed prefix
+  // renumbered automaton
+  uint32_t nStates = 0;      // reachable
+  uint32_t init = 0;         // device index of the initial state (initialOff_)
+  uint32_t leaderNext = 0;   // device index of the state after the leader (leaderOff_)
+  uint32_t nPureDead = 0;
+  uint32_t firstAccept = 0;
+  int32_t  maxResult = 0;
+  bool     deadAbsorbing = true;  // every pure dead end self-loops on every class
+  std::vector<int32_t>  result;   // [nStates]
+  std::vector<uint32_t> next;     // [nStates][nClasses], device indices
+  // table chosen for the device
+  uint32_t tableKind = 0;         // REDGPU_TAB_*
+  std::vector<uint8_t> table;     // packed bytes of that table
+};
+
+// lib/Serializer.cpp:270-298, message text verbatim; nullptr when the header is good.
+const char *checkHeader(const void *ptr, size_t len);
+
+// include/Fnv.h:36-66 (32-bit), lib/Serializer.cpp:301-306
+uint32_t fnv1a32(const void *ptr, size_t len);
+uint32_t calcChecksum(const void *ptr, size_t len);
+
+// Parses + bounds-checks + renumbers.  Returns "" on success, else the error message
+// (code: REDGPU_EAPI for a bad blob, REDGPU_ELIMIT for capacity).
+std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool forceGlobal,
+                       DfaImage &img, int &errCode);
+
+} // namespace redgpu

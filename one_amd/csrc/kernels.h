@@ -1,0 +1,53 @@
+// kernels.h - launch interface between the C-ABI (redgpu.cpp) and the gfx950 kernels.
+#pragma once
+
+#include <cstdint>
+
+#include <hip/hip_runtime.h>
+
+namespace redgpu {
+
+enum Verb : int { kCheck = 0, kMatch = 1, kScan = 2 };
+
+// Device-resident DFA image (pointers are device addresses). Built once per redgpu_dfa.
+struct DevDfa {
+  const uint8_t *table;    // packed table, layout per tableKind (REDGPU_TAB_*)
+  const int32_t *result;   // [nStates] result code per device state
+  const uint8_t *equivLeader; // 256 bytes equivalence map, then 256 bytes class-space leader
+  uint32_t tableKind;
+  uint32_t tableBytes;
+  uint32_t nStates;
+  uint32_t nClasses;
+  uint32_t init;
+  uint32_t leaderNext;
+  uint32_t nPureDead;
+  uint32_t firstAccept;
+  uint32_t leaderLen;
+  uint32_t deadAbsorbing;
+};
+
+// One batch of lines (device pointers).
+struct Batch {
+  const uint8_t  *data;
+  const uint64_t *offsets; // n+1 entries, or nullptr => fixed stride
+  uint64_t stride;
+  uint64_t n;
+  int32_t  *result;
+  uint64_t *start;         // may be nullptr
+  uint64_t *end;           // may be nullptr
+};
+
+struct LaunchCfg {
+  int numCUs;
+  int forceGeneric;
+};
+
+// Launches the kernel for (verb, style, doLeader) on `stream`; returns hipSuccess or the
+// launch error. *kernelName receives a static string naming the kernel chosen.
+hipError_t launchBatch(const DevDfa &dfa, const Batch &b, int verb, int style, int doLeader,
+                       const LaunchCfg &cfg, hipStream_t stream, const char **kernelName);
+
+// True when the specialised fixed-stride kernels can run this DFA at all.
+bool fastPathEligible(const DevDfa &dfa);
+
+} // namespace redgpu

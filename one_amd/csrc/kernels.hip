@@ -1,0 +1,587 @@
+// kernels.hip - hand-written gfx950 (CDNA4 / MI355X) kernels for RED's DFA match execution.
+//
+// What is restated here, one input line per lane (citations relative to
+// /root/reference/quol/red/):
+//   checkCore  include/Matcher.h:363-410      matchCore  include/Matcher.h:413-495
+//   scanCore   include/Matcher.h:498-554      lookingAt / compareThrough  :333-360
+//   the per-byte step DfaProxy::next/result/pureDeadEnd   include/Proxy.h:131-147
+// over the renumbered device image of dfa_image.h (s < nPureDead <=> pureDeadEnd,
+// s >= firstAccept <=> result > 0, so the per-byte predicates are integer compares).
+//
+// Two families:
+//   k_generic<KIND>   any verb / style / doLeader / ragged or fixed lines / any table placement.
+//                     The correctness workhorse (and the path for DFAs that do not fit LDS).
+//   k_fixed<...>      the hot path of BASELINE.json: fixed-stride lines, fused [state][byte]
+//                     u8 table resident in LDS (one ds_read_u8 per input byte, no equivalence
+//                     lookup), several independent lines per lane for LDS-latency cover,
+//                     16-byte global loads, coalesced SoA result stores.  No MFMA: this is a
+//                     gather workload bounded by HBM input streaming and the LDS gather rate.
+#include "kernels.h"
+
+#include "../../include/redgpu.h"
+
+namespace redgpu {
+
+namespace {
+
+constexpr int kStyInstant = REDGPU_STY_INSTANT;
+constexpr int kStyFirst = REDGPU_STY_FIRST;
+constexpr int kStyTangent = REDGPU_STY_TANGENT;
+constexpr int kStyLast = REDGPU_STY_LAST;
+constexpr int kStyFull = REDGPU_STY_FULL;
+
+// ---- table accessors -------------------------------------------------------------------
+template <int KIND> struct Tab;
+
+template <> struct Tab<REDGPU_TAB_LDS_FUSED_U8> {
+  static constexpr bool kInLds = true;
+  const uint8_t *t;
+  __device__ Tab(const uint8_t *tab, const uint8_t *, uint32_t) : t(tab) {}
+  __device__ __forceinline__ uint32_t next(uint32_t s, uint32_t byte) const {
+    return t[(s << 8) | byte];
+  }
+};
+
+template <> struct Tab<REDGPU_TAB_LDS_FUSED_U16> {
+  static constexpr bool kInLds = true;
+  const uint16_t *t;
+  __device__ Tab(const uint8_t *tab, const uint8_t *, uint32_t)
+      : t(reinterpret_cast<const uint16_t *>(tab)) {}
+  __device__ __forceinline__ uint32_t next(uint32_t s, uint32_t byte) const {
+    return t[(s << 8) | byte];
+  }
+};
+
+template <> struct Tab<REDGPU_TAB_LDS_CLASS_U16> {
+  static constexpr bool kInLds = true;
+  const uint16_t *t;
+  const uint8_t *eq;
+  uint32_t nc;
+  __device__ Tab(const uint8_t *tab, const uint8_t *equiv, uint32_t nClasses)
+      : t(reinterpret_cast<const uint16_t *>(tab)), eq(equiv), nc(nClasses) {}
+  __device__ __forceinline__ uint32_t next(uint32_t s, uint32_t byte) const {
+    return t[s * nc + eq[byte]];
+  }
+};
+
+template <> struct Tab<REDGPU_TAB_GLOBAL_U16> {
+  static constexpr bool kInLds = false;
+  const uint16_t *t;
+  const uint8_t *eq;
+  uint32_t nc;
+  __device__ Tab(const uint8_t *tab, const uint8_t *equiv, uint32_t nClasses)
+      : t(reinterpret_cast<const uint16_t *>(tab)), eq(equiv), nc(nClasses) {}
+  __device__ __forceinline__ uint32_t next(uint32_t s, uint32_t byte) const {
+    return t[size_t(s) * nc + eq[byte]];
+  }
+};
+
+template <> struct Tab<REDGPU_TAB_GLOBAL_U32> {
+  static constexpr bool kInLds = false;
+  const uint32_t *t;
+  const uint8_t *eq;
+  uint32_t nc;
+  __device__ Tab(const uint8_t *tab, const uint8_t *equiv, uint32_t nClasses)
+      : t(reinterpret_cast<const uint32_t *>(tab)), eq(equiv), nc(nClasses) {}
+  __device__ __forceinline__ uint32_t next(uint32_t s, uint32_t byte) const {
+    return t[size_t(s) * nc + eq[byte]];
+  }
+};
+
+struct LaneCtx {
+  const uint8_t *eq;      // LDS: byte -> class
+  const uint8_t *leader;  // LDS: class-space leader
+  const int32_t *res;     // global: result per device state
+  uint32_t init, leaderNext, nPureDead, firstAccept, leaderLen;
+  __device__ __forceinline__ int32_t resultOf(uint32_t s) const {
+    return s >= firstAccept ? res[s] : 0;
+  }
+};
+
+// include/Matcher.h:333-345 lookingAt: cursor by value, nothing consumed
+__device__ __forceinline__ bool lookingAt(const LaneCtx &c, const uint8_t *p, uint64_t i,
+                                          uint64_t n) {
+  for (uint32_t k = 0; k < c.leaderLen; ++k, ++i) {
+    if (i >= n) return false;
+    if (c.leader[k] != c.eq[p[i]]) return false;
+  }
+  return true;
+}
+
+// include/Matcher.h:348-360 compareThrough: cursor by reference; on a mismatch the cursor
+// stays AT the mismatching byte (the return precedes the increment)
+__device__ __forceinline__ bool compareThrough(const LaneCtx &c, const uint8_t *p, uint64_t &i,
+                                               uint64_t n) {
+  for (uint32_t k = 0; k < c.leaderLen; ++k, ++i) {
+    if (i >= n) return false;
+    if (c.leader[k] != c.eq[p[i]]) return false;
+  }
+  return true;
+}
+
+// include/Matcher.h:363-410
+template <class T>
+__device__ int32_t checkLane(const T &tab, const LaneCtx &c, const uint8_t *p, uint64_t n,
+                             int style, bool lead) {
+  uint64_t i = 0;
+  uint32_t s;
+  if (lead) {
+    if (!compareThrough(c, p, i, n)) return 0;
+    s = c.leaderNext;
+  } else
+    s = c.init;
+  int32_t result = c.resultOf(s);
+  int32_t prev = 0;
+  for (; i < n; ++i) {
+    s = tab.next(s, p[i]);
+    if (s >= c.firstAccept) {
+      result = c.res[s];
+      if (style == kStyInstant) return result;
+      if (style == kStyFirst) {
+        if (prev && result != prev) return prev;
+        prev = result;
+      }
+      if (style == kStyTangent || style == kStyLast) prev = result;
+    } else {
+      result = 0;
+      if ((style == kStyFirst || style == kStyTangent) && prev > 0) return prev;
+      if (s < c.nPureDead) break;
+    }
+  }
+  if (style == kStyLast && result == 0 && prev > 0) return prev;
+  return result;
+}
+
+// include/Matcher.h:413-495
+template <class T>
+__device__ int32_t matchLane(const T &tab, const LaneCtx &c, const uint8_t *p, uint64_t n,
+                             int style, bool lead, uint64_t &startOut, uint64_t &endOut) {
+  startOut = 0;
+  endOut = 0;
+  if (lead && !lookingAt(c, p, 0, n)) return 0;
+  uint32_t s = c.init;
+  int32_t result = c.resultOf(s);
+  int32_t prev = 0;
+  uint64_t matchStart = 0, matchEnd = 0;
+  for (uint64_t idx = 0; idx < n; ++idx) {
+    const uint32_t was = s;
+    s = tab.next(s, p[idx]);
+    if (was == c.init && s != was) matchStart = idx;  // "escaped the initial state" :446-451
+    if (s >= c.firstAccept) {
+      result = c.res[s];
+      if (style == kStyFirst) {
+        if (prev && result != prev) { result = prev; break; }
+        prev = result;
+      }
+      matchEnd = idx + 1;
+      if (style == kStyInstant) break;
+      if (style == kStyTangent || style == kStyLast) prev = result;
+    } else {
+      result = 0;
+      if (style == kStyFirst && prev > 0) { result = prev; break; }
+      if (style == kStyTangent && prev > 0) break;
+      if (s < c.nPureDead) break;
+    }
+  }
+  if ((style == kStyTangent || style == kStyLast) && result == 0 && prev > 0) result = prev;
+  if (result != 0) {
+    startOut = matchStart;
+    endOut = matchEnd;
+  }
+  return result;
+}
+
+// include/Matcher.h:498-554
+template <class T>
+__device__ int32_t scanLane(const T &tab, const LaneCtx &c, const uint8_t *p, uint64_t n,
+                            int style, bool lead) {
+  int32_t result = c.resultOf(c.init);
+  for (uint64_t i = 0; i < n; ++i) {
+    uint32_t s;
+    if (lead) {
+      if (!compareThrough(c, p, i, n)) continue;  // i sits on the mismatching byte; ++i skips it
+      s = c.leaderNext;
+      result = c.resultOf(s);
+    } else
+      s = c.init;
+    int32_t prev = 0;
+    for (uint64_t q = i; q < n; ++q) {
+      s = tab.next(s, p[q]);
+      if (s >= c.firstAccept) {
+        result = c.res[s];
+        if (style == kStyInstant) return result;
+        if (style == kStyFirst) {
+          if (prev && result != prev) return prev;
+          prev = result;
+        }
+        if (style == kStyTangent || style == kStyLast) prev = result;
+      } else {
+        result = 0;
+        if ((style == kStyFirst || style == kStyTangent) && prev > 0) return prev;
+        if (s < c.nPureDead) break;
+      }
+    }
+    if (style == kStyLast && result == 0 && prev > 0) return prev;
+    if (result > 0) return result;
+  }
+  return result;
+}
+
+constexpr int kGenericThreads = 256;
+
+// dynamic LDS: [equiv 256][leader 256][table (LDS kinds only)]
+template <int KIND>
+__global__ void __launch_bounds__(kGenericThreads)
+k_generic(DevDfa d, Batch b, int verb, int style, int lead) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  uint8_t *eq = lds;
+  uint8_t *leader = lds + 256;
+  uint8_t *ldsTab = lds + 512;
+  for (uint32_t i = threadIdx.x; i < 512 / 4; i += kGenericThreads)
+    reinterpret_cast<uint32_t *>(lds)[i] = reinterpret_cast<const uint32_t *>(d.equivLeader)[i];
+  if (Tab<KIND>::kInLds) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(d.table);
+    uint4 *dst = reinterpret_cast<uint4 *>(ldsTab);
+    for (uint32_t i = threadIdx.x; i < d.tableBytes / 16; i += kGenericThreads) dst[i] = src[i];
+  }
+  __syncthreads();
+
+  const Tab<KIND> tab(Tab<KIND>::kInLds ? ldsTab : d.table, eq, d.nClasses);
+  LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
+            d.leaderLen};
+
+  const uint64_t step = uint64_t(gridDim.x) * kGenericThreads;
+  for (uint64_t line = uint64_t(blockIdx.x) * kGenericThreads + threadIdx.x; line < b.n;
+       line += step) {
+    const uint8_t *p;
+    uint64_t n;
+    if (b.offsets) {
+      const uint64_t o = b.offsets[line];
+      p = b.data + o;
+      n = b.offsets[line + 1] - o;
+    } else {
+      p = b.data + line * b.stride;
+      n = b.stride;
+    }
+    if (verb == kCheck) {
+      b.result[line] = checkLane(tab, c, p, n, style, lead != 0);
+    } else if (verb == kScan) {
+      b.result[line] = scanLane(tab, c, p, n, style, lead != 0);
+    } else {
+      uint64_t st, en;
+      b.result[line] = matchLane(tab, c, p, n, style, lead != 0, st, en);
+      if (b.start) b.start[line] = st;
+      if (b.end) b.end[line] = en;
+    }
+  }
+}
+
+// =========================================================================================
+// The hot path: fixed-stride lines, fused u8 table in LDS.
+//
+// Layout in LDS: [table nStates*256 B][result nStates*4 B].  One workgroup of 1024 threads
+// (16 waves) per CU shares one copy of the table; each lane walks CHAINS independent lines
+// (line = tile*1024*CHAINS + chain*1024 + thread) so that CHAINS ds_read_u8 are in flight per
+// lane while each chain's own lookup->lookup dependency (~64+ cycles of LDS latency) resolves.
+// Per input byte and chain: 1 VALU to form the LDS address ((state << 8) | byte),
+// 1 ds_read_u8, and 2-5 VALU of style bookkeeping.  Styles Last and Full never leave the loop
+// early (a pure dead end is absorbing - verified on the host - so walking on is a no-op),
+// which keeps the wave uniform.  Early-exit styles freeze the lane's bookkeeping instead.
+// =========================================================================================
+constexpr int kFixedThreads = 1024;
+
+template <int STYLE, bool POS, bool WANT_START>
+struct ChainState {
+  uint32_t s;        // current device state
+  uint32_t accS;     // last accepting state seen (valid when endv != 0)
+  uint32_t endv;     // idx+1 of the last accept (0 = none yet)
+  uint32_t startv;   // idx at which the walk last escaped the initial state
+  uint32_t wasInit;  // s == init before this step
+  uint32_t live;     // early-exit styles: 0 once the reference loop would have left
+};
+
+template <int STYLE, bool POS, bool WANT_START>
+__device__ __forceinline__ void stepChain(ChainState<STYLE, POS, WANT_START> &c,
+                                          const uint8_t *__restrict__ tab, uint32_t byte,
+                                          uint32_t idx, uint32_t init, uint32_t firstAccept,
+                                          const int32_t *__restrict__ ldsRes) {
+  const uint32_t sNew = tab[(c.s << 8) | byte];
+  if (STYLE == kStyLast || STYLE == kStyFull) {
+    if (POS && WANT_START) {
+      const uint32_t isInit = (sNew == init);
+      c.startv = (c.wasInit && !isInit) ? idx : c.startv;
+      c.wasInit = isInit;
+    }
+    if (STYLE == kStyLast) {
+      const bool acc = sNew >= firstAccept;
+      c.accS = acc ? sNew : c.accS;
+      c.endv = acc ? idx + 1 : c.endv;
+    }
+    c.s = sNew;
+  } else {
+    // Instant / First / Tangent: once the reference would `break`/`return`, stop updating.
+    if (c.live) {
+      if (POS && WANT_START) {
+        const uint32_t isInit = (sNew == init);
+        if (c.wasInit && !isInit) c.startv = idx;
+        c.wasInit = isInit;
+      }
+      c.s = sNew;
+      if (sNew >= firstAccept) {
+        if (STYLE == kStyFirst && c.endv && ldsRes[sNew] != ldsRes[c.accS]) {
+          c.live = 0;  // result changed: keep the previous accept (Matcher.h:457-460)
+        } else {
+          c.accS = sNew;
+          c.endv = idx + 1;
+          if (STYLE == kStyInstant) c.live = 0;
+        }
+      } else if (c.endv) {
+        c.live = 0;  // First/Tangent: left the accepting run (Matcher.h:470-475)
+      }
+    }
+  }
+}
+
+template <int STYLE, bool POS, bool WANT_START, int CHAINS>
+__global__ void __launch_bounds__(kFixedThreads)
+k_fixed(DevDfa d, Batch b, uint32_t lineLen, uint32_t startByte, uint32_t startState) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  uint8_t *tab = lds;
+  int32_t *ldsRes = reinterpret_cast<int32_t *>(lds + d.tableBytes);
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(d.table);
+    uint4 *dst = reinterpret_cast<uint4 *>(tab);
+    for (uint32_t i = threadIdx.x; i < d.tableBytes / 16; i += kFixedThreads) dst[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < d.nStates; i += kFixedThreads) ldsRes[i] = d.result[i];
+  }
+  __syncthreads();
+
+  const uint32_t init = d.init;
+  const uint32_t firstAccept = d.firstAccept;
+  const uint64_t linesPerTile = uint64_t(kFixedThreads) * CHAINS;
+  const uint64_t nTiles = (b.n + linesPerTile - 1) / linesPerTile;
+
+  for (uint64_t tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+    ChainState<STYLE, POS, WANT_START> cs[CHAINS];
+    const uint8_t *lp[CHAINS];
+    uint64_t line[CHAINS];
+    bool valid[CHAINS];
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) {
+      line[c] = tile * linesPerTile + uint64_t(c) * kFixedThreads + threadIdx.x;
+      valid[c] = line[c] < b.n;
+      // out-of-range chains re-walk the last line and are not stored: keeps the wave uniform
+      const uint64_t ln = valid[c] ? line[c] : b.n - 1;
+      lp[c] = b.data + ln * b.stride;
+      cs[c].s = startState;
+      cs[c].accS = 0;
+      cs[c].endv = 0;
+      cs[c].startv = 0;
+      cs[c].wasInit = (startState == init);
+      cs[c].live = 1;
+    }
+
+    // 16 bytes per chain per round, next round's loads issued before this round's walk
+    uint4 cur[CHAINS];
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c)
+      cur[c] = *reinterpret_cast<const uint4 *>(lp[c] + startByte);
+
+    for (uint32_t off = startByte; off < lineLen; off += 16) {
+      uint4 nxt[CHAINS];
+      const bool more = off + 16 < lineLen;
+      if (more) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c)
+          nxt[c] = *reinterpret_cast<const uint4 *>(lp[c] + off + 16);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int c = 0; c < CHAINS; ++c) {
+            const uint32_t word = k == 0 ? cur[c].x : k == 1 ? cur[c].y : k == 2 ? cur[c].z
+                                                                                   : cur[c].w;
+            const uint32_t byte = (word >> (8 * j)) & 0xffu;
+            stepChain<STYLE, POS, WANT_START>(cs[c], tab, byte, off + 4 * k + j, init,
+                                              firstAccept, ldsRes);
+          }
+        }
+      }
+      if (more) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) cur[c] = nxt[c];
+      }
+    }
+
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) {
+      if (!valid[c]) continue;
+      int32_t r;
+      uint32_t en;
+      if (STYLE == kStyFull) {
+        // result of the final state; end is the line length when it accepts (Matcher.h:463)
+        r = cs[c].s >= firstAccept ? ldsRes[cs[c].s] : 0;
+        en = lineLen;
+      } else {
+        r = cs[c].endv ? ldsRes[cs[c].accS] : 0;
+        en = cs[c].endv;
+      }
+      b.result[line[c]] = r;
+      if (POS) {
+        if (b.end) b.end[line[c]] = r ? uint64_t(en) : 0;
+        if (WANT_START && b.start) b.start[line[c]] = r ? uint64_t(cs[c].startv) : 0;
+      }
+    }
+  }
+}
+
+// leader pre-pass for the fixed kernels: marks lines whose first leaderLen bytes do not
+// match the fixed prefix (lookingAt / compareThrough, Matcher.h:333-360) by zeroing outputs.
+__global__ void __launch_bounds__(256)
+k_leader_filter(DevDfa d, Batch b) {
+  __shared__ uint8_t eq[512];
+  for (uint32_t i = threadIdx.x; i < 128; i += 256)
+    reinterpret_cast<uint32_t *>(eq)[i] = reinterpret_cast<const uint32_t *>(d.equivLeader)[i];
+  __syncthreads();
+  const uint8_t *leader = eq + 256;
+  const uint64_t step = uint64_t(gridDim.x) * 256;
+  for (uint64_t line = uint64_t(blockIdx.x) * 256 + threadIdx.x; line < b.n; line += step) {
+    const uint8_t *p = b.data + line * b.stride;
+    bool ok = d.leaderLen <= b.stride;
+    for (uint32_t k = 0; ok && k < d.leaderLen; ++k) ok = leader[k] == eq[p[k]];
+    if (!ok) {
+      b.result[line] = 0;
+      if (b.start) b.start[line] = 0;
+      if (b.end) b.end[line] = 0;
+    }
+  }
+}
+
+template <class K>
+hipError_t setLds(K kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
+}
+
+template <int KIND>
+hipError_t launchGeneric(const DevDfa &d, const Batch &b, int verb, int style, int lead,
+                         const LaunchCfg &cfg, hipStream_t stream) {
+  const size_t ldsBytes = 512 + (Tab<KIND>::kInLds ? size_t(d.tableBytes) : 0);
+  hipError_t e = setLds(k_generic<KIND>, ldsBytes);
+  if (e != hipSuccess) return e;
+  uint64_t blocks = (b.n + kGenericThreads - 1) / kGenericThreads;
+  // an LDS-resident table is re-staged per block: keep the grid near one wave of blocks
+  const uint64_t cap = uint64_t(cfg.numCUs) * (Tab<KIND>::kInLds ? 2 : 8);
+  if (blocks > cap) blocks = cap;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(k_generic<KIND>, dim3(uint32_t(blocks)), dim3(kGenericThreads), ldsBytes,
+                     stream, d, b, verb, style, lead);
+  return hipGetLastError();
+}
+
+template <int STYLE, bool POS, bool WANT_START, int CHAINS>
+hipError_t launchFixedT(const DevDfa &d, const Batch &b, uint32_t startByte,
+                        uint32_t startState, const LaunchCfg &cfg, hipStream_t stream) {
+  auto kern = k_fixed<STYLE, POS, WANT_START, CHAINS>;
+  const size_t ldsBytes = size_t(d.tableBytes) + size_t(d.nStates) * 4;
+  hipError_t e = setLds(kern, ldsBytes);
+  if (e != hipSuccess) return e;
+  const uint64_t linesPerTile = uint64_t(kFixedThreads) * CHAINS;
+  uint64_t tiles = (b.n + linesPerTile - 1) / linesPerTile;
+  uint64_t blocks = tiles < uint64_t(cfg.numCUs) ? tiles : uint64_t(cfg.numCUs);
+  hipLaunchKernelGGL(kern, dim3(uint32_t(blocks)), dim3(kFixedThreads), ldsBytes, stream, d, b,
+                     uint32_t(b.stride), startByte, startState);
+  return hipGetLastError();
+}
+
+template <int STYLE, bool POS, bool WANT_START>
+hipError_t launchFixedC(const DevDfa &d, const Batch &b, uint32_t startByte,
+                        uint32_t startState, const LaunchCfg &cfg, hipStream_t stream) {
+  // enough chains per lane to give every CU one full tile; small batches use fewer chains
+  const uint64_t perCu = b.n / (uint64_t(cfg.numCUs) * kFixedThreads);
+  if (perCu >= 4)
+    return launchFixedT<STYLE, POS, WANT_START, 4>(d, b, startByte, startState, cfg, stream);
+  if (perCu >= 2)
+    return launchFixedT<STYLE, POS, WANT_START, 2>(d, b, startByte, startState, cfg, stream);
+  return launchFixedT<STYLE, POS, WANT_START, 1>(d, b, startByte, startState, cfg, stream);
+}
+
+template <bool POS, bool WANT_START>
+hipError_t launchFixedS(int style, const DevDfa &d, const Batch &b, uint32_t startByte,
+                        uint32_t startState, const LaunchCfg &cfg, hipStream_t stream) {
+  switch (style) {
+  case kStyInstant:
+    return launchFixedC<kStyInstant, POS, WANT_START>(d, b, startByte, startState, cfg, stream);
+  case kStyFirst:
+    return launchFixedC<kStyFirst, POS, WANT_START>(d, b, startByte, startState, cfg, stream);
+  case kStyTangent:
+    return launchFixedC<kStyTangent, POS, WANT_START>(d, b, startByte, startState, cfg, stream);
+  case kStyLast:
+    return launchFixedC<kStyLast, POS, WANT_START>(d, b, startByte, startState, cfg, stream);
+  default:
+    return launchFixedC<kStyFull, POS, WANT_START>(d, b, startByte, startState, cfg, stream);
+  }
+}
+
+} // namespace
+
+bool fastPathEligible(const DevDfa &d) {
+  return d.tableKind == REDGPU_TAB_LDS_FUSED_U8 && d.deadAbsorbing &&
+         size_t(d.tableBytes) + size_t(d.nStates) * 4 <= 150 * 1024;
+}
+
+hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int doLeader,
+                       const LaunchCfg &cfg, hipStream_t stream, const char **kernelName) {
+  if (b.n == 0) {
+    *kernelName = "none";
+    return hipSuccess;
+  }
+  const bool lead = doLeader && d.leaderLen > 0;
+  // Fixed-stride hot path: check / match, whole 16-byte multiples, 16-byte aligned base.
+  // check<.., true> consumes the leader and starts in the post-leader state at byte
+  // leaderLen (Matcher.h:370-375); match only peeks it (Matcher.h:424-435).
+  const bool fixedOk = !cfg.forceGeneric && fastPathEligible(d) && !b.offsets &&
+                       (verb == kCheck || verb == kMatch) && b.stride >= 16 &&
+                       b.stride % 16 == 0 && b.stride < (1ull << 31) &&
+                       (reinterpret_cast<uintptr_t>(b.data) % 16) == 0 &&
+                       !(lead && verb == kCheck);
+  if (fixedOk) {
+    hipError_t e;
+    if (verb == kCheck) {
+      *kernelName = "k_fixed<check>";
+      e = launchFixedS<false, false>(style, d, b, 0, d.init, cfg, stream);
+    } else if (b.start) {
+      *kernelName = "k_fixed<match,start>";
+      e = launchFixedS<true, true>(style, d, b, 0, d.init, cfg, stream);
+    } else {
+      *kernelName = "k_fixed<match>";
+      e = launchFixedS<true, false>(style, d, b, 0, d.init, cfg, stream);
+    }
+    if (e != hipSuccess) return e;
+    if (lead) {
+      hipLaunchKernelGGL(k_leader_filter, dim3(uint32_t(cfg.numCUs) * 8), dim3(256), 0, stream,
+                         d, b);
+      return hipGetLastError();
+    }
+    return hipSuccess;
+  }
+
+  *kernelName = "k_generic";
+  switch (d.tableKind) {
+  case REDGPU_TAB_LDS_FUSED_U8:
+    return launchGeneric<REDGPU_TAB_LDS_FUSED_U8>(d, b, verb, style, lead, cfg, stream);
+  case REDGPU_TAB_LDS_FUSED_U16:
+    return launchGeneric<REDGPU_TAB_LDS_FUSED_U16>(d, b, verb, style, lead, cfg, stream);
+  case REDGPU_TAB_LDS_CLASS_U16:
+    return launchGeneric<REDGPU_TAB_LDS_CLASS_U16>(d, b, verb, style, lead, cfg, stream);
+  case REDGPU_TAB_GLOBAL_U16:
+    return launchGeneric<REDGPU_TAB_GLOBAL_U16>(d, b, verb, style, lead, cfg, stream);
+  default:
+    return launchGeneric<REDGPU_TAB_GLOBAL_U32>(d, b, verb, style, lead, cfg, stream);
+  }
+}
+
+} // namespace redgpu

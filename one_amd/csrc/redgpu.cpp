@@ -1,0 +1,333 @@
+// redgpu.cpp - the C-ABI of include/redgpu.h over the gfx950 kernels.  Host C++ (built with
+// hipcc for the HIP runtime API).  There is no CPU compute path in this file or behind it:
+// every batch entry point either launches a kernel or fails.
+#include "../../include/redgpu.h"
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "dfa_image.h"
+#include "kernels.h"
+
+using namespace redgpu;
+
+struct redgpu_dfa {
+  std::vector<uint8_t> blob;  // our own copy (Executable(gCopyTag,..) semantics)
+  DfaImage img;
+  int device = REDGPU_DEVICE_NONE;
+  int numCUs = 0;
+  uint32_t flags = 0;
+  // device allocations
+  void *dTable = nullptr;
+  void *dResult = nullptr;
+  void *dEquivLeader = nullptr;
+  DevDfa dev{};
+};
+
+namespace {
+
+thread_local std::string tlsError;
+thread_local const char *tlsKernel = "";
+
+int fail(int code, const std::string &msg) {
+  tlsError = msg;
+  return code;
+}
+
+int failHip(hipError_t e, const char *what) {
+  tlsError = std::string(what) + ": " + hipGetErrorString(e);
+  return REDGPU_EHIP;
+}
+
+#define HIP_TRY(expr, what)                          \
+  do {                                               \
+    hipError_t e_ = (expr);                          \
+    if (e_ != hipSuccess) return failHip(e_, what);  \
+  } while (0)
+
+// RAII: run on the handle's device, restore the caller's current device afterwards
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceScope(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) {
+      err = hipSetDevice(dev);
+      switched = (err == hipSuccess);
+    }
+  }
+  ~DeviceScope() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+int checkStyle(int style) {
+  if (style < REDGPU_STY_INSTANT || style > REDGPU_STY_FULL)
+    return fail(REDGPU_EEXEC, "unsupported style");  // lib/Matcher.cpp:45
+  return REDGPU_OK;
+}
+
+int runDev(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint8_t *data,
+           const uint64_t *offsets, uint64_t stride, uint64_t n, int32_t *result,
+           uint64_t *start, uint64_t *end, hipStream_t stream) {
+  if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
+  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (int rc = checkStyle(style)) return rc;
+  if (n == 0) return REDGPU_OK;
+  if (!result) return fail(REDGPU_EAPI, "null result buffer");
+  if (!data && (offsets || stride)) return fail(REDGPU_EAPI, "null data buffer");
+  if (!offsets && stride >= (1ull << 40)) return fail(REDGPU_ELIMIT, "stride too large");
+  DeviceScope scope(dfa->device);
+  if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  Batch b{data, offsets, stride, n, result, start, end};
+  LaunchCfg cfg{dfa->numCUs, (dfa->flags & REDGPU_F_FORCE_GENERIC) ? 1 : 0};
+  const char *name = "";
+  hipError_t e = launchBatch(dfa->dev, b, verb, style, doLeader ? 1 : 0, cfg, stream, &name);
+  tlsKernel = name;
+  if (e != hipSuccess) return failHip(e, "kernel launch");
+  return REDGPU_OK;
+}
+
+// host-buffer form: stage through device memory on a private stream
+int runHost(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint8_t *data,
+            const uint64_t *offsets, uint64_t stride, uint64_t n, int32_t *result,
+            uint64_t *start, uint64_t *end) {
+  if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
+  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (int rc = checkStyle(style)) return rc;
+  if (n == 0) return REDGPU_OK;
+  if (!result) return fail(REDGPU_EAPI, "null result buffer");
+  uint64_t total = offsets ? offsets[n] : stride * n;
+  if (offsets) {
+    for (uint64_t i = 0; i < n; ++i)
+      if (offsets[i] > offsets[i + 1]) return fail(REDGPU_EAPI, "offsets not monotonic");
+  }
+  if (total && !data) return fail(REDGPU_EAPI, "null data buffer");
+  DeviceScope scope(dfa->device);
+  if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+
+  hipStream_t s = nullptr;
+  uint8_t *dData = nullptr;
+  uint64_t *dOff = nullptr, *dStart = nullptr, *dEnd = nullptr;
+  int32_t *dRes = nullptr;
+  int rc = REDGPU_OK;
+  auto cleanup = [&]() {
+    if (dData) (void)hipFree(dData);
+    if (dOff) (void)hipFree(dOff);
+    if (dRes) (void)hipFree(dRes);
+    if (dStart) (void)hipFree(dStart);
+    if (dEnd) (void)hipFree(dEnd);
+    if (s) (void)hipStreamDestroy(s);
+  };
+#define HOST_TRY(expr, what)                                         \
+  do {                                                               \
+    hipError_t e_ = (expr);                                          \
+    if (e_ != hipSuccess) { rc = failHip(e_, what); cleanup(); return rc; } \
+  } while (0)
+  HOST_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+  // +16 so that 16-byte loads of the last line never leave the allocation
+  HOST_TRY(hipMalloc(reinterpret_cast<void **>(&dData), total + 16), "hipMalloc data");
+  HOST_TRY(hipMalloc(reinterpret_cast<void **>(&dRes), n * sizeof(int32_t)), "hipMalloc result");
+  if (offsets) {
+    HOST_TRY(hipMalloc(reinterpret_cast<void **>(&dOff), (n + 1) * sizeof(uint64_t)),
+             "hipMalloc offsets");
+    HOST_TRY(hipMemcpyAsync(dOff, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s),
+             "copy offsets");
+  }
+  if (start) HOST_TRY(hipMalloc(reinterpret_cast<void **>(&dStart), n * 8), "hipMalloc start");
+  if (end) HOST_TRY(hipMalloc(reinterpret_cast<void **>(&dEnd), n * 8), "hipMalloc end");
+  if (total)
+    HOST_TRY(hipMemcpyAsync(dData, data, total, hipMemcpyHostToDevice, s), "copy data");
+  rc = runDev(dfa, verb, style, doLeader, dData, dOff, stride, n, dRes, dStart, dEnd, s);
+  if (rc != REDGPU_OK) { cleanup(); return rc; }
+  HOST_TRY(hipMemcpyAsync(result, dRes, n * sizeof(int32_t), hipMemcpyDeviceToHost, s),
+           "copy result");
+  if (start) HOST_TRY(hipMemcpyAsync(start, dStart, n * 8, hipMemcpyDeviceToHost, s), "copy start");
+  if (end) HOST_TRY(hipMemcpyAsync(end, dEnd, n * 8, hipMemcpyDeviceToHost, s), "copy end");
+  HOST_TRY(hipStreamSynchronize(s), "hipStreamSynchronize");
+#undef HOST_TRY
+  cleanup();
+  return REDGPU_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int redgpu_version(void) { return 100; }
+
+const char *redgpu_last_error(void) { return tlsError.c_str(); }
+
+const char *redgpu_last_kernel(void) { return tlsKernel; }
+
+int redgpu_reda_check(const void *reda, size_t len, const char **msg) {
+  const char *m = (reda && len) ? checkHeader(reda, len) : "serialized dfa is empty";
+  if (msg) *msg = m;
+  if (m) return fail(REDGPU_EAPI, m);
+  return REDGPU_OK;
+}
+
+int redgpu_dfa_create(const void *reda, size_t len, const redgpu_opts *opts, redgpu_dfa **out) {
+  if (!out) return fail(REDGPU_EAPI, "null output handle");
+  *out = nullptr;
+  redgpu_opts o{};
+  o.device = REDGPU_DEVICE_CURRENT;
+  if (opts) o = *opts;
+
+  redgpu_dfa *h = new (std::nothrow) redgpu_dfa();
+  if (!h) return fail(REDGPU_ELIMIT, "out of host memory");
+  int code = REDGPU_OK;
+  std::string err = buildImage(reda, len, o.lds_table_max, (o.flags & REDGPU_F_FORCE_GLOBAL) != 0,
+                               h->img, code);
+  if (!err.empty()) {
+    delete h;
+    return fail(code, err);
+  }
+  h->blob.assign(static_cast<const uint8_t *>(reda), static_cast<const uint8_t *>(reda) + len);
+  h->flags = o.flags;
+  if (o.device == REDGPU_DEVICE_NONE) {
+    h->device = REDGPU_DEVICE_NONE;
+    *out = h;
+    return REDGPU_OK;
+  }
+
+  int dev = o.device;
+  if (dev == REDGPU_DEVICE_CURRENT) {
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { delete h; return failHip(e, "hipGetDevice"); }
+  }
+  DeviceScope scope(dev);
+  if (scope.err != hipSuccess) { delete h; return failHip(scope.err, "hipSetDevice"); }
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, dev);
+  if (e != hipSuccess) { delete h; return failHip(e, "hipGetDeviceProperties"); }
+  h->device = dev;
+  h->numCUs = prop.multiProcessorCount;
+
+  const DfaImage &img = h->img;
+  uint8_t eqLead[512];
+  std::memcpy(eqLead, img.equiv, 256);
+  std::memcpy(eqLead + 256, img.leader, 256);
+  const size_t tabBytes = (img.table.size() + 15) & ~size_t(15);
+  auto bail = [&](hipError_t er, const char *what) {
+    int rc = failHip(er, what);
+    redgpu_dfa_destroy(h);
+    return rc;
+  };
+  if ((e = hipMalloc(&h->dTable, tabBytes + 16)) != hipSuccess) return bail(e, "hipMalloc table");
+  if ((e = hipMalloc(&h->dResult, img.nStates * sizeof(int32_t) + 16)) != hipSuccess)
+    return bail(e, "hipMalloc result");
+  if ((e = hipMalloc(&h->dEquivLeader, 512)) != hipSuccess) return bail(e, "hipMalloc equiv");
+  if ((e = hipMemset(h->dTable, 0, tabBytes + 16)) != hipSuccess) return bail(e, "hipMemset");
+  if ((e = hipMemcpy(h->dTable, img.table.data(), img.table.size(), hipMemcpyHostToDevice)) !=
+      hipSuccess)
+    return bail(e, "upload table");
+  if ((e = hipMemcpy(h->dResult, img.result.data(), img.nStates * sizeof(int32_t),
+                     hipMemcpyHostToDevice)) != hipSuccess)
+    return bail(e, "upload result");
+  if ((e = hipMemcpy(h->dEquivLeader, eqLead, 512, hipMemcpyHostToDevice)) != hipSuccess)
+    return bail(e, "upload equiv");
+
+  DevDfa &d = h->dev;
+  d.table = static_cast<const uint8_t *>(h->dTable);
+  d.result = static_cast<const int32_t *>(h->dResult);
+  d.equivLeader = static_cast<const uint8_t *>(h->dEquivLeader);
+  d.tableKind = img.tableKind;
+  d.tableBytes = uint32_t(tabBytes);
+  d.nStates = img.nStates;
+  d.nClasses = img.nClasses;
+  d.init = img.init;
+  d.leaderNext = img.leaderNext;
+  d.nPureDead = img.nPureDead;
+  d.firstAccept = img.firstAccept;
+  d.leaderLen = img.leaderLen;
+  d.deadAbsorbing = img.deadAbsorbing ? 1 : 0;
+  *out = h;
+  return REDGPU_OK;
+}
+
+void redgpu_dfa_destroy(redgpu_dfa *h) {
+  if (!h) return;
+  if (h->device >= 0) {
+    DeviceScope scope(h->device);
+    if (h->dTable) (void)hipFree(h->dTable);
+    if (h->dResult) (void)hipFree(h->dResult);
+    if (h->dEquivLeader) (void)hipFree(h->dEquivLeader);
+  }
+  delete h;
+}
+
+int redgpu_dfa_info(const redgpu_dfa *h, redgpu_info *out) {
+  if (!h || !out) return fail(REDGPU_EAPI, "null argument");
+  const DfaImage &img = h->img;
+  out->format = img.format;
+  out->n_classes = img.nClasses;
+  out->leader_len = img.leaderLen;
+  out->states_total = img.statesTotal;
+  out->states_used = img.nStates;
+  out->n_pure_dead = img.nPureDead;
+  out->first_accept = img.firstAccept;
+  out->table_kind = img.tableKind;
+  out->table_bytes = img.table.size();
+  out->max_result = img.maxResult;
+  out->device = h->device;
+  out->checksum = img.checksum;
+  out->fast_path = (img.tableKind == REDGPU_TAB_LDS_FUSED_U8 && img.deadAbsorbing &&
+                    !(h->flags & REDGPU_F_FORCE_GENERIC)) ? 1 : 0;
+  return REDGPU_OK;
+}
+
+int redgpu_dfa_serialized(const redgpu_dfa *h, const void **reda, size_t *len) {
+  if (!h || !reda || !len) return fail(REDGPU_EAPI, "null argument");
+  *reda = h->blob.data();
+  *len = h->blob.size();
+  return REDGPU_OK;
+}
+
+int redgpu_check_batch(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                       const uint64_t *offsets, uint64_t stride, uint64_t n, int32_t *result) {
+  return runHost(dfa, kCheck, style, do_leader, data, offsets, stride, n, result, nullptr,
+                 nullptr);
+}
+
+int redgpu_match_batch(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                       const uint64_t *offsets, uint64_t stride, uint64_t n, int32_t *result,
+                       uint64_t *start, uint64_t *end) {
+  return runHost(dfa, kMatch, style, do_leader, data, offsets, stride, n, result, start, end);
+}
+
+int redgpu_scan_batch(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                      const uint64_t *offsets, uint64_t stride, uint64_t n, int32_t *result) {
+  return runHost(dfa, kScan, style, do_leader, data, offsets, stride, n, result, nullptr,
+                 nullptr);
+}
+
+int redgpu_check_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                           const uint64_t *offsets, uint64_t stride, uint64_t n,
+                           int32_t *result, void *stream) {
+  return runDev(dfa, kCheck, style, do_leader, data, offsets, stride, n, result, nullptr,
+                nullptr, static_cast<hipStream_t>(stream));
+}
+
+int redgpu_match_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                           const uint64_t *offsets, uint64_t stride, uint64_t n,
+                           int32_t *result, uint64_t *start, uint64_t *end, void *stream) {
+  return runDev(dfa, kMatch, style, do_leader, data, offsets, stride, n, result, start, end,
+                static_cast<hipStream_t>(stream));
+}
+
+int redgpu_scan_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                          const uint64_t *offsets, uint64_t stride, uint64_t n, int32_t *result,
+                          void *stream) {
+  return runDev(dfa, kScan, style, do_leader, data, offsets, stride, n, result, nullptr,
+                nullptr, static_cast<hipStream_t>(stream));
+}
+
+} // extern "C"

@@ -1,0 +1,225 @@
+"""Host-side mirror of the reference's matcher interface for the batch path.
+
+Names follow /root/reference/quol/red: `Executable` (include/Executable.h:28-76), `Style`
+(include/Matcher.h:67-74), `Outcome` fields result/start/end (include/Outcome.h:32-35), verbs
+`check` / `match` / `scan` (include/Matcher.h:79-92,133-169) and the exception classes of
+include/Except.h.  Everything here is plumbing over the C-ABI (include/redgpu.h): inputs may be
+host arrays (numpy / bytes -> the library stages them) or torch tensors resident on the GPU
+(-> the *_dev entry points, asynchronous on torch's current stream).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+
+import numpy as np
+
+from . import _lib
+
+
+class Style(enum.IntEnum):  # include/Matcher.h:67-74
+    styInvalid = 0
+    styInstant = 1
+    styFirst = 2
+    styTangent = 3
+    styLast = 4
+    styFull = 5
+
+
+styInstant, styFirst, styTangent, styLast, styFull = (Style.styInstant, Style.styFirst,
+                                                      Style.styTangent, Style.styLast,
+                                                      Style.styFull)
+
+
+# include/Except.h:9-19
+class RedExcept(RuntimeError):
+    pass
+
+
+class RedExceptApi(RedExcept):
+    pass
+
+
+class RedExceptExec(RedExcept):
+    pass
+
+
+class RedExceptLimit(RedExcept):
+    pass
+
+
+class RedExceptHip(RedExceptExec):
+    """HIP runtime / device failure (no reference analogue)."""
+
+
+_EXC = {_lib.EAPI: RedExceptApi, _lib.EEXEC: RedExceptExec, _lib.ELIMIT: RedExceptLimit,
+        _lib.EHIP: RedExceptHip}
+
+
+def _check(rc: int) -> None:
+    if rc != _lib.OK:
+        msg = _lib.lib().redgpu_last_error().decode()
+        raise _EXC.get(rc, RedExcept)(msg)
+
+
+def check_header(blob: bytes):
+    """checkHeader (lib/Serializer.cpp:270-298): None when good, else the message."""
+    msg = C.c_char_p()
+    rc = _lib.lib().redgpu_reda_check(blob, len(blob), C.byref(msg))
+    return None if rc == _lib.OK else msg.value.decode()
+
+
+class Executable:
+    """A validated serialized DFA uploaded to one GPU (mirrors zezax::red::Executable).
+
+    device: HIP ordinal, None = current device, "none" = host-only handle (validate + repack,
+    no HIP call; batch verbs on it raise RedExceptApi)."""
+
+    def __init__(self, serialized: bytes, device=None, *, force_generic=False,
+                 force_global=False, lds_table_max=0):
+        if serialized is None or len(serialized) == 0:
+            raise RedExceptApi("serialized dfa string_view is empty")  # Executable.cpp:66
+        o = _lib.Opts()
+        o.device = (_lib.DEVICE_NONE if device == "none" else
+                    _lib.DEVICE_CURRENT if device is None else int(device))
+        o.lds_table_max = lds_table_max
+        o.flags = (_lib.F_FORCE_GENERIC if force_generic else 0) | \
+                  (_lib.F_FORCE_GLOBAL if force_global else 0)
+        self._h = C.c_void_p()
+        blob = bytes(serialized)
+        _check(_lib.lib().redgpu_dfa_create(blob, len(blob), C.byref(o), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().redgpu_dfa_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def info(self) -> dict:
+        i = _lib.Info()
+        _check(_lib.lib().redgpu_dfa_info(self._h, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in _lib.Info._fields_}
+
+    def serialized(self) -> bytes:
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(_lib.lib().redgpu_dfa_serialized(self._h, C.byref(p), C.byref(n)))
+        return C.string_at(p.value, n.value)
+
+
+def last_kernel() -> str:
+    return _lib.lib().redgpu_last_kernel().decode()
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.split(".")[0] == "torch"
+
+
+def _host_u8(data) -> np.ndarray:
+    if isinstance(data, (bytes, bytearray, memoryview)):
+        return np.frombuffer(bytes(data), dtype=np.uint8)
+    a = np.ascontiguousarray(data)
+    if a.dtype != np.uint8:
+        raise RedExceptApi("input bytes must be uint8")
+    return a
+
+
+def _run(verb: str, exe: Executable, style, do_leader, data, offsets, stride, n, want_start,
+         want_end, out=None):
+    """Returns (result, start, end); start/end are None when not requested / not a match verb."""
+    l = _lib.lib()
+    style = int(style)
+    lead = 1 if do_leader else 0
+    if _is_torch(data):
+        import torch
+        if not data.is_cuda or data.dtype != torch.uint8 or not data.is_contiguous():
+            raise RedExceptApi("device input must be a contiguous uint8 CUDA tensor")
+        dev = data.device
+        if offsets is not None:
+            if (not _is_torch(offsets) or offsets.dtype not in (torch.int64, torch.uint64)
+                    or not offsets.is_cuda or not offsets.is_contiguous()):
+                raise RedExceptApi("device offsets must be a contiguous int64 CUDA tensor")
+            n = offsets.numel() - 1
+            stride = 0
+        elif n is None:
+            n = data.numel() // stride if stride else 0
+        if out is None:
+            res = torch.empty(n, dtype=torch.int32, device=dev)
+            st = torch.empty(n, dtype=torch.int64, device=dev) if want_start else None
+            en = torch.empty(n, dtype=torch.int64, device=dev) if want_end else None
+        else:
+            res, st, en = out
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        op = offsets.data_ptr() if offsets is not None else None
+        if verb == "match":
+            rc = l.redgpu_match_batch_dev(exe._h, style, lead, data.data_ptr(), op, stride, n,
+                                          res.data_ptr(),
+                                          st.data_ptr() if st is not None else None,
+                                          en.data_ptr() if en is not None else None, stream)
+        else:
+            f = l.redgpu_check_batch_dev if verb == "check" else l.redgpu_scan_batch_dev
+            rc = f(exe._h, style, lead, data.data_ptr(), op, stride, n, res.data_ptr(), stream)
+        _check(rc)
+        return res, st, en
+
+    a = _host_u8(data)
+    if offsets is not None:
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        stride = 0
+        if len(offsets) and int(offsets[-1]) > a.size:
+            raise RedExceptApi("offsets run past the data buffer")
+    else:
+        if n is None:
+            n = a.size // stride if stride else 0
+        if stride * n > a.size:
+            raise RedExceptApi("stride * n runs past the data buffer")
+    res = np.zeros(n, dtype=np.int32)
+    st = np.zeros(n, dtype=np.uint64) if want_start else None
+    en = np.zeros(n, dtype=np.uint64) if want_end else None
+    op = offsets.ctypes.data if offsets is not None else None
+    dp = a.ctypes.data if a.size else None
+    if verb == "match":
+        rc = l.redgpu_match_batch(exe._h, style, lead, dp, op, stride, n, res.ctypes.data,
+                                  st.ctypes.data if st is not None else None,
+                                  en.ctypes.data if en is not None else None)
+    else:
+        f = l.redgpu_check_batch if verb == "check" else l.redgpu_scan_batch
+        rc = f(exe._h, style, lead, dp, op, stride, n, res.ctypes.data)
+    _check(rc)
+    return res, st, en
+
+
+def check_batch(exe, data, style, do_leader=True, *, offsets=None, stride=0, n=None, out=None):
+    """check<style,doLeader> over every line (include/Matcher.h:363-410) -> result int32[n]."""
+    return _run("check", exe, style, do_leader, data, offsets, stride, n, False, False,
+                None if out is None else (out, None, None))[0]
+
+
+def scan_batch(exe, data, style, do_leader=True, *, offsets=None, stride=0, n=None, out=None):
+    """scan<style,doLeader> over every line (include/Matcher.h:498-554) -> result int32[n]."""
+    return _run("scan", exe, style, do_leader, data, offsets, stride, n, False, False,
+                None if out is None else (out, None, None))[0]
+
+
+def match_batch(exe, data, style, do_leader=True, *, offsets=None, stride=0, n=None,
+                want_start=True, want_end=True, out=None):
+    """match<style,doLeader> over every line (include/Matcher.h:413-495) ->
+    (result int32[n], start uint64[n] | None, end uint64[n] | None), the Outcome fields."""
+    return _run("match", exe, style, do_leader, data, offsets, stride, n, want_start, want_end,
+                out)
+
+
+# single-input forms keep the reference's signatures; they are batches of one ON THE GPU
+def check(exe, text: bytes, style, do_leader=True) -> int:
+    return int(check_batch(exe, text, style, do_leader, offsets=[0, len(text)])[0])
+
+
+def scan(exe, text: bytes, style, do_leader=True) -> int:
+    return int(scan_batch(exe, text, style, do_leader, offsets=[0, len(text)])[0])
+
+
+def match(exe, text: bytes, style, do_leader=True):
+    r, s, e = match_batch(exe, text, style, do_leader, offsets=[0, len(text)])
+    return int(r[0]), int(s[0]), int(e[0])

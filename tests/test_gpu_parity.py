@@ -1,0 +1,235 @@
+"""GPU parity: the HIP path (through the C-ABI) against the golden vectors and against the CPU
+oracle on seeded inputs.  Bit-exact: result codes, start and end offsets are integers."""
+import numpy as np
+import pytest
+
+import one_amd
+import oracle as O
+from golden_util import (CONFIG_DFAS, STYLES, expect_of, kat_items, load_dfa, load_omnibus,
+                         load_vectors, unb64)
+from oracle.reda_writer import random_dfa
+from one_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+STY = {"instant": 1, "first": 2, "tangent": 3, "last": 4, "full": 5}
+
+
+def _gpu_call(exe, verb, style, lead, text):
+    if verb == "check":
+        return one_amd.check(exe, text, STY[style], lead)
+    if verb == "scan":
+        return one_amd.scan(exe, text, STY[style], lead)
+    return one_amd.match(exe, text, STY[style], lead)
+
+
+def test_native_library_is_loaded():
+    from one_amd import _lib
+    assert _lib.lib().redgpu_version() >= 100
+    exe = one_amd.Executable(load_dfa("err"))
+    assert exe.info["device"] >= 0
+
+
+def test_kat_matcher_cpp_on_gpu():
+    """Known answers asserted by the reference's test/matcher.cpp (check / match / scan rows)."""
+    n = 0
+    for name, fmt, blob, calls in kat_items():
+        exe = one_amd.Executable(blob)
+        for c in calls:
+            if c["verb"] == "search":
+                continue  # searchCore is a "next" row
+            got = _gpu_call(exe, c["verb"], c["style"], c["lead"], unb64(c["text"]))
+            exp = c["expect"]
+            if isinstance(exp, int):
+                assert got == exp, (name, fmt, c, got)
+            else:
+                for g, e in zip(got, exp):
+                    assert e is None or g == e, (name, fmt, c, got)
+            n += 1
+    assert n > 250
+
+
+def test_omnibus_table_on_gpu():
+    """test/omnibus.cpp:506-555: check(styFull) == match(styFull).result_ == expectation."""
+    rows, blobs = load_omnibus()
+    checked = 0
+    for r in rows:
+        for fmt, key in r["fmt"].items():
+            if key in ("limit", "parse", "err"):
+                continue
+            exe = one_amd.Executable(blobs[key].tobytes())
+            text = unb64(r["text"]).split(b"\0")[0]
+            res = one_amd.check(exe, text, one_amd.styFull, True)
+            oc = one_amd.match(exe, text, one_amd.styFull, True)
+            assert res == oc[0] and (res == 1) == r["match"], (r, fmt, res, oc)
+            checked += 1
+    assert checked > 500
+
+
+@pytest.mark.parametrize("mode", ["default", "generic", "global"])
+@pytest.mark.parametrize("name", CONFIG_DFAS)
+def test_reference_vectors_on_gpu(name, mode):
+    """Reference outputs for every verb x style x doLeader on the ragged mixed input set."""
+    vec = load_vectors(name)
+    exe = one_amd.Executable(load_dfa(name), force_generic=(mode == "generic"),
+                             force_global=(mode == "global"))
+    data, offsets = vec["data"], vec["offsets"]
+    for verb in ("check", "match", "scan"):
+        for si in range(1, 6):
+            for lead in (0, 1):
+                er, es, ee = expect_of(vec, verb, si, lead)
+                if verb == "match":
+                    r, s, e = one_amd.match_batch(exe, data, si, lead, offsets=offsets)
+                    assert np.array_equal(s, es) and np.array_equal(e, ee), (name, verb, si, lead)
+                elif verb == "check":
+                    r = one_amd.check_batch(exe, data, si, lead, offsets=offsets)
+                else:
+                    r = one_amd.scan_batch(exe, data, si, lead, offsets=offsets)
+                assert np.array_equal(r, er), (name, verb, si, lead)
+
+
+def _fixed_inputs(name, n, stride, seed):
+    if name == "syn256":
+        return W.fixed_lines(n, stride, seed, alphabet=False)
+    plant = {"uri": W.URI_PLANT, "err": b"error", "num3": b"123abcd ", "newyork": b"New York",
+             "aab": b"aab", "dotstar_err": b"an error"}[name]
+    buf = W.fixed_lines(n, stride, seed, plant=plant, plant_every=3, plant_at=min(7, stride - 8))
+    v = buf.reshape(n, stride)
+    v[1::5, :len(plant[:stride])] = np.frombuffer(plant[:stride], dtype=np.uint8)  # at line start
+    return buf
+
+
+@pytest.mark.parametrize("stride,n", [(64, 5000), (16, 1500), (4096, 300), (48, 2049),
+                                      (64, 1024 * 4 * 3 + 17)])
+@pytest.mark.parametrize("name", ["syn256", "uri", "err", "num3", "newyork", "dotstar_err"])
+def test_fixed_stride_hot_path_vs_oracle(name, stride, n):
+    """The specialised fixed-stride kernels (k_fixed) against the oracle, all styles, check and
+    match, with and without the leader, ragged tile counts."""
+    blob = load_dfa(name)
+    exe = one_amd.Executable(blob)
+    cpu = O.CpuOracle(blob)
+    data = _fixed_inputs(name, n, stride, seed=stride + n)
+    for si in range(1, 6):
+        for lead in (0, 1):
+            er, es, ee = cpu.batch("match", si, lead, data, stride=stride, n=n, threads=4)
+            r, s, e = one_amd.match_batch(exe, data, si, lead, stride=stride, n=n)
+            assert np.array_equal(r, er), (name, "match", si, lead)
+            assert np.array_equal(s, es) and np.array_equal(e, ee), (name, "match", si, lead)
+            r2, _, e2 = one_amd.match_batch(exe, data, si, lead, stride=stride, n=n,
+                                            want_start=False)
+            assert np.array_equal(r2, er) and np.array_equal(e2, ee)
+            cr, _, _ = cpu.batch("check", si, lead, data, stride=stride, n=n, threads=4)
+            assert np.array_equal(one_amd.check_batch(exe, data, si, lead, stride=stride, n=n), cr)
+    if exe.info["fast_path"]:
+        one_amd.match_batch(exe, data, 4, 0, stride=stride, n=n)
+        assert one_amd.last_kernel().startswith("k_fixed"), one_amd.last_kernel()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_dfas_vs_oracle(seed):
+    """Synthetic DFAs of every table placement (incl. reachable pure dead ends) vs the oracle."""
+    n_states = [3, 60, 256, 257, 700, 5000][seed]
+    n_cls = [2, 256, 256, 30, 64, 9][seed]
+    blob = random_dfa(n_states, n_cls, seed, dead_frac=[0.3, 0.0, 0.02, 0.0, 0.05, 0.1][seed])
+    exe = one_amd.Executable(blob)
+    cpu = O.CpuOracle(blob)
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, 120, 3000)
+    offsets = np.zeros(len(lens) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    data = rng.integers(0, 256, int(offsets[-1]), dtype=np.uint8)
+    fixed = rng.integers(0, 256, 2000 * 32, dtype=np.uint8)
+    for si in range(1, 6):
+        for lead in (0, 1):
+            er, es, ee = cpu.batch("match", si, lead, data, offsets=offsets, threads=4)
+            r, s, e = one_amd.match_batch(exe, data, si, lead, offsets=offsets)
+            assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee)
+            assert np.array_equal(one_amd.check_batch(exe, data, si, lead, offsets=offsets),
+                                  cpu.batch("check", si, lead, data, offsets=offsets)[0])
+            assert np.array_equal(one_amd.scan_batch(exe, data, si, lead, offsets=offsets),
+                                  cpu.batch("scan", si, lead, data, offsets=offsets, threads=4)[0])
+            er, es, ee = cpu.batch("match", si, lead, fixed, stride=32, n=2000)
+            r, s, e = one_amd.match_batch(exe, fixed, si, lead, stride=32, n=2000)
+            assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee)
+
+
+def test_edge_cases():
+    exe = one_amd.Executable(load_dfa("err"))
+    cpu = O.CpuOracle(load_dfa("err"))
+    # empty batch
+    assert len(one_amd.check_batch(exe, b"", 4, offsets=[0])) == 0
+    assert len(one_amd.match_batch(exe, b"", 4, stride=64, n=0)[0]) == 0
+    # all-empty lines, and lines shorter than the 5-byte leader
+    offs = np.array([0, 0, 0, 3, 3, 8, 13], dtype=np.uint64)
+    data = b"err" + b"error" + b"errox"
+    for verb, fn in (("check", one_amd.check_batch), ("scan", one_amd.scan_batch)):
+        for si in range(1, 6):
+            for lead in (0, 1):
+                assert np.array_equal(fn(exe, data, si, lead, offsets=offs),
+                                      cpu.batch(verb, si, lead, np.frombuffer(data, np.uint8),
+                                                offsets=offs)[0])
+    # accepting initial state is reported for empty input only (SURVEY a-M quirk 2)
+    import json
+    for name, fmt, blob, calls in kat_items():
+        if name == "quirk_accepting_initial":
+            e2 = one_amd.Executable(blob)
+            assert one_amd.match(e2, b"", 4, False) == (1, 0, 0)
+            assert one_amd.match(e2, b"b", 4, False) == (0, 0, 0)
+    # unsupported style -> RedExceptExec (lib/Matcher.cpp:45)
+    with pytest.raises(one_amd.RedExceptExec, match="unsupported style"):
+        one_amd.check_batch(exe, b"error", 9, offsets=[0, 5])
+    with pytest.raises(one_amd.RedExceptExec):
+        one_amd.match_batch(exe, b"error", 0, offsets=[0, 5])
+
+
+def test_long_single_line_positions():
+    """One 3 MiB line: positions beyond 2^16 / 2^21, generic path (ragged) and fixed path."""
+    blob = load_dfa("dotstar_err")
+    exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
+    n = 3 * 1024 * 1024
+    data = W.alphabet_bytes(n, 77)
+    data[n - 100000:n - 100000 + 5] = np.frombuffer(b"error", np.uint8)
+    for si in (3, 4, 5):
+        er = cpu.match(data.tobytes(), si, False)
+        assert one_amd.match_batch(exe, data, si, 0, offsets=[0, n]) [0][0] == er[0]
+        r, s, e = one_amd.match_batch(exe, data, si, 0, stride=n, n=1)
+        assert (int(r[0]), int(s[0]), int(e[0])) == er
+
+
+def test_device_resident_api_with_torch():
+    import torch
+    blob = load_dfa("syn256")
+    exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
+    n, stride = 4096 * 3 + 5, 64
+    host = W.fixed_lines(n, stride, 9, alphabet=False)
+    dev = torch.from_numpy(host).cuda()
+    r, s, e = one_amd.match_batch(exe, dev, 4, 0, stride=stride, n=n)
+    torch.cuda.synchronize()
+    er, es, ee = cpu.batch("match", 4, 0, host, stride=stride, n=n, threads=4)
+    assert np.array_equal(r.cpu().numpy(), er)
+    assert np.array_equal(s.cpu().numpy().astype(np.uint64), es)
+    assert np.array_equal(e.cpu().numpy().astype(np.uint64), ee)
+    offs = torch.arange(0, n + 1, dtype=torch.int64, device="cuda") * stride
+    r2 = one_amd.check_batch(exe, dev, 5, 1, offsets=offs)
+    torch.cuda.synchronize()
+    assert np.array_equal(r2.cpu().numpy(), cpu.batch("check", 5, 1, host, stride=stride, n=n)[0])
+
+
+def test_full_size_config2_bit_exact():
+    """BASELINE config 2 at full size: 2^20 lines x 64 B, SYN-256 and URI-D, match<styLast,false>,
+    compared line-for-line with the oracle (8 host threads)."""
+    n, stride = 1 << 20, 64
+    for name in ("syn256", "uri"):
+        blob = load_dfa(name)
+        exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
+        data = (W.fixed_lines(n, stride, 42, alphabet=False) if name == "syn256" else
+                W.fixed_lines(n, stride, 2, plant=W.URI_PLANT))
+        r, s, e = one_amd.match_batch(exe, data, 4, 0, stride=stride, n=n)
+        er, es, ee = cpu.batch("match", 4, 0, data, stride=stride, n=n, threads=8)
+        assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee)
+        assert int((r > 0).sum()) > 1000
+        # size-independent property: the batch result equals the concatenation of its halves
+        h = n // 2
+        r1 = one_amd.match_batch(exe, data[:h * stride], 4, 0, stride=stride, n=h)[0]
+        r2 = one_amd.match_batch(exe, data[h * stride:], 4, 0, stride=stride, n=h)[0]
+        assert np.array_equal(np.concatenate([r1, r2]), r)

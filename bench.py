@@ -10,9 +10,11 @@ Workload at every N = BASELINE.json configs[1], per GPU: the 256-state / 256-cla
 (tests/golden/dfas/syn256.reda, produced by the reference's minimizer + serializer) over
 2^20 lines x 64 B = 64 MiB of uniform random bytes; >= 5 distinct input buffers are rotated so
 that no step finds its input in the 256 MiB Infinity Cache.  N > 1: one process per GPU,
-weak scaling (every rank scans its own shard, no data-path collective); the per-line results
-are gathered to rank 0 over RCCL in compact form, overlapped with the following steps, and the
-last gather completes inside the timed region.
+weak scaling (every rank scans its own shard, no data-path collective); the final step's
+per-line Outcomes are gathered to rank 0 over RCCL (compact wire records, widened on rank 0)
+once, at the end, INSIDE the timed region - "RCCL over xGMI only for the final result gather".
+(A gather after every step cannot scale for 64-byte lines: 3 bytes of results per 64 bytes of
+input is 1/21 of the scan rate per GPU, well above what an xGMI link carries - DESIGN.md.)
 
 Prints ONE JSON line on rank 0 (see the driver's contract) with `roofline` (dominant kernel
 vs the 8 TB/s HBM peak, timed with events on the launch stream) and `cpu_baseline` (the
@@ -44,8 +46,9 @@ def parse_args():
     ap.add_argument("--no-start", action="store_true", help="outputs result + end only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--gather-every", type=int, default=8,
-                    help="N>1: steps per RCCL result gather")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the steps are issued on round-robin (independent batches "
+                         "overlap: one step's ramp-up hides under the previous step's tail)")
     return ap.parse_args()
 
 
@@ -131,9 +134,20 @@ def main():
              torch.empty(n, dtype=torch.int64, device="cuda") if want_start else None,
              torch.empty(n, dtype=torch.int64, device="cuda")) for _ in range(nout)]
 
+    streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else None
+    nout = max(nout, 2 * args.streams)
+    while len(outs) < nout:
+        outs.append((torch.empty(n, dtype=torch.int32, device="cuda"),
+                     torch.empty(n, dtype=torch.int64, device="cuda") if want_start else None,
+                     torch.empty(n, dtype=torch.int64, device="cuda")))
+
     def step(i):
-        return one_amd.match_batch(exe, bufs[i % len(bufs)], one_amd.styLast, False, stride=L,
-                                   n=n, want_start=want_start, out=outs[i % nout])
+        if streams is None:
+            return one_amd.match_batch(exe, bufs[i % len(bufs)], one_amd.styLast, False,
+                                       stride=L, n=n, want_start=want_start, out=outs[i % nout])
+        with torch.cuda.stream(streams[i % len(streams)]):
+            return one_amd.match_batch(exe, bufs[i % len(bufs)], one_amd.styLast, False,
+                                       stride=L, n=n, want_start=want_start, out=outs[i % nout])
 
     # ---- correctness gate: buffer 0 bit-exact against the CPU oracle ------------------------
     import oracle
@@ -150,13 +164,12 @@ def main():
     gather = None
     if world > 1:
         from one_amd import sharding
-        gather = sharding.ResultGather(n, args.gather_every, world, rank, L, info["max_result"],
-                                       want_start)
+        gather = sharding.FinalGather(info["max_result"], L, want_start)
 
     for i in range(args.warmup):
         o = step(i)
         if gather:
-            gather.push(i, o)
+            gather.push(o)
     if gather:
         gather.flush()
     torch.cuda.synchronize()
@@ -170,10 +183,13 @@ def main():
     for i in range(args.steps):
         o = step(i)
         if gather:
-            gather.push(i, o)
+            gather.push(o)
+    if streams is not None:
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
     ev1.record()
     if gather:
-        gather.flush()
+        gather.flush()  # the final result gather: inside the timed region
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -189,10 +205,12 @@ def main():
     # ---- dominant kernel, per launch, with events on the launch stream ----------------------
     # (separate loop so that the event records do not sit inside the timed region)
     kms = []
+    torch.cuda.synchronize()
     for i in range(min(args.steps, 100)):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        step(i)
+        one_amd.match_batch(exe, bufs[i % len(bufs)], one_amd.styLast, False, stride=L, n=n,
+                            want_start=want_start, out=outs[i % nout])
         b.record()
         kms.append((a, b))
     torch.cuda.synchronize()
@@ -207,7 +225,7 @@ def main():
     # roofline: algorithmic input bytes per launch / average duration of the launch.  The
     # back-to-back figure (events around the whole timed region / K) includes launch gaps and
     # is the conservative one we report as `achieved`.
-    kernel_ms = back_to_back_ms if world == 1 else k_avg_ms
+    kernel_ms = back_to_back_ms if (world == 1 and args.streams == 1) else k_avg_ms
     achieved = bytes_per_step / (kernel_ms * 1e-3) / 1e9
     line = {
         "metric": "GB/s input scanned (and Minput/s) for fixed DFA",
@@ -228,8 +246,9 @@ def main():
                         (args.dfa, info["states_used"], info["n_classes"], info["format"], n, L,
                          "result+start+end" if want_start else "result+end"),
             "lines_per_gpu": n, "line_len": L, "rotating_input_buffers": len(bufs),
+            "streams": args.streams,
             "sharding": "contiguous shard per GPU, no data-path collective" +
-                        ("; RCCL gather of compact results every %d steps" % args.gather_every
+                        ("; one final RCCL gather of the last step's Outcomes to rank 0"
                          if world > 1 else ""),
         },
         "minputs_per_s": round(world * args.steps * n / elapsed / 1e6, 1),

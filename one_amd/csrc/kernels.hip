@@ -459,6 +459,8 @@ k_leader_filter(DevDfa d, Batch b) {
   }
 }
 
+#include "k_stream.h"
+
 template <class K>
 hipError_t setLds(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return hipSuccess;
@@ -548,6 +550,28 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
                        b.stride % 16 == 0 && b.stride < (1ull << 31) &&
                        (reinterpret_cast<uintptr_t>(b.data) % 16) == 0 &&
                        !(lead && verb == kCheck);
+  // Streaming kernel: styles Last / Full on lines that are whole 64-byte blocks.
+  const bool streamOk = fixedOk && (style == kStyLast || style == kStyFull) &&
+                        b.stride % 64 == 0 && d.tableBytes <= kStreamTabBytes && d.nStates <= 256;
+  if (streamOk) {
+    hipError_t e;
+    Batch sb = b;
+    if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
+    if (style == kStyLast) {
+      if (sb.start) { *kernelName = "k_stream<last,start,end>"; e = launchStreamT<kSmLastStartEnd>(d, sb, cfg, stream); }
+      else { *kernelName = "k_stream<last,end>"; e = launchStreamT<kSmLastEnd>(d, sb, cfg, stream); }
+    } else {
+      if (sb.start) { *kernelName = "k_stream<full,start>"; e = launchStreamT<kSmFullStart>(d, sb, cfg, stream); }
+      else { *kernelName = "k_stream<full>"; e = launchStreamT<kSmFull>(d, sb, cfg, stream); }
+    }
+    if (e != hipSuccess) return e;
+    if (lead) {
+      hipLaunchKernelGGL(k_leader_filter, dim3(uint32_t(cfg.numCUs) * 8), dim3(256), 0, stream,
+                         d, b);
+      return hipGetLastError();
+    }
+    return hipSuccess;
+  }
   if (fixedOk) {
     hipError_t e;
     if (verb == kCheck) {

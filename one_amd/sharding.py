@@ -1,0 +1,166 @@
+"""Multi-GPU plumbing: one process per GPU, contiguous shards, result gather over RCCL.
+
+The reference has no distributed layer (its only concurrency is N std::threads over one shared
+read-only Executable, tools/thr_red.cpp:86-91).  Here the batch of input lines is cut into
+contiguous index ranges, one per rank; every rank scans its own shard with its own copy of the
+DFA image (no data-path collective), and the per-line Outcome fields are gathered to rank 0
+once, at the end - `torch.distributed` backend "nccl" (= RCCL over xGMI) for device tensors,
+"gloo" for the CPU rehearsal in tests.
+
+Wire format: xGMI is point-to-point (7 links x ~50-60 GB/s usable per direction into the
+root), so records travel in the narrowest integer type that holds them - result in 1/2/4
+bytes by the DFA's max result, start/end in 1/2/4/8 bytes by the longest line - and are widened
+on rank 0 back to the reference's Outcome types (int32 result, 64-bit start/end), bit-exact.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_lines: int, world: int, rank: int) -> tuple[int, int]:
+    """Contiguous [lo, hi) of lines for `rank`: sizes differ by at most one line."""
+    base, extra = divmod(n_lines, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_range_by_bytes(offsets: torch.Tensor, world: int, rank: int) -> tuple[int, int]:
+    """Contiguous [lo, hi) of lines for `rank`, balanced by BYTES for ragged lines
+    (offsets: int64[n+1], monotone)."""
+    n = offsets.numel() - 1
+    total = int(offsets[-1])
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r // world
+        cuts.append(int(torch.searchsorted(offsets[: n + 1].contiguous(),
+                                           torch.tensor([target], dtype=offsets.dtype,
+                                                        device=offsets.device)).item()))
+    cuts.append(n)
+    cuts = [min(max(c, 0), n) for c in cuts]
+    for i in range(1, len(cuts)):
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return cuts[rank], cuts[rank + 1]
+
+
+def _width_for(max_value: int) -> int:
+    for w, lim in ((1, 0xFF), (2, 0xFFFF), (4, 0xFFFFFFFF)):
+        if max_value <= lim:
+            return w
+    return 8
+
+
+_DT = {1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}
+_MASK = {1: 0xFF, 2: 0xFFFF, 4: 0xFFFFFFFF}
+
+
+def _narrow(t: torch.Tensor, width: int) -> torch.Tensor:
+    """int32/int64 values known to fit `width` bytes -> raw little-endian bytes [n, width]."""
+    if width == 8:
+        return t.to(torch.int64).contiguous().view(torch.uint8).view(-1, 8)
+    if width == 1:
+        return t.to(torch.uint8).view(-1, 1)
+    # two's-complement wrap keeps the low bytes; the widener masks them back to unsigned
+    return t.to(_DT[width]).contiguous().view(torch.uint8).view(-1, width)
+
+
+def _widen(b: torch.Tensor, width: int, out_dtype) -> torch.Tensor:
+    if width == 8:
+        return b.contiguous().view(torch.int64).view(-1).to(out_dtype)
+    if width == 1:
+        return b.contiguous().view(-1).to(out_dtype)
+    v = b.contiguous().view(_DT[width]).view(-1).to(torch.int64) & _MASK[width]
+    return v.to(out_dtype)
+
+
+class RecordFormat:
+    """Compact per-line record: [result | start | end], little-endian, fixed widths."""
+
+    def __init__(self, max_result: int, max_line_len: int, with_start: bool = True):
+        self.rw = _width_for(max(int(max_result), 0))
+        self.pw = _width_for(max(int(max_line_len), 0))
+        self.with_start = with_start
+        self.bytes = self.rw + self.pw * (2 if with_start else 1)
+
+    def pack(self, result, start, end) -> torch.Tensor:
+        parts = [_narrow(result, self.rw)]
+        if self.with_start:
+            parts.append(_narrow(start, self.pw))
+        parts.append(_narrow(end, self.pw))
+        return torch.cat(parts, dim=1).contiguous()
+
+    def unpack(self, rec: torch.Tensor):
+        rec = rec.view(-1, self.bytes)
+        o = 0
+        result = _widen(rec[:, o:o + self.rw], self.rw, torch.int32)
+        o += self.rw
+        start = None
+        if self.with_start:
+            start = _widen(rec[:, o:o + self.pw], self.pw, torch.int64)
+            o += self.pw
+        end = _widen(rec[:, o:o + self.pw], self.pw, torch.int64)
+        return result, start, end
+
+
+def gather_outcomes(result, start, end, *, max_result: int, max_line_len: int, dst: int = 0,
+                    group=None, async_op: bool = False):
+    """Gathers every rank's per-line (result, start, end) to rank `dst`, in rank order.
+
+    All ranks pass tensors on the same kind of device (CUDA -> RCCL, CPU -> gloo); shard sizes
+    may differ.  Returns on `dst` a callable `finish()` -> (result int32[N], start int64[N] |
+    None, end int64[N]) covering all shards concatenated; on other ranks `finish()` -> None.
+    With async_op=False the collective has completed when this function returns."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    fmt = RecordFormat(max_result, max_line_len, with_start=start is not None)
+    rec = fmt.pack(result, start, end)
+    n_local = torch.tensor([rec.shape[0]], dtype=torch.int64, device=rec.device)
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local, group=group)
+    counts = [int(c.item()) for c in counts]
+    n_max = max(counts) if counts else 0
+    # equal-size gather (one collective, every link busy at once); pad the short shards
+    padded = rec
+    if rec.shape[0] < n_max:
+        padded = torch.zeros((n_max, fmt.bytes), dtype=torch.uint8, device=rec.device)
+        padded[: rec.shape[0]] = rec
+    bufs = None
+    if rank == dst:
+        bufs = [torch.empty((n_max, fmt.bytes), dtype=torch.uint8, device=rec.device)
+                for _ in range(world)]
+    work = dist.gather(padded, gather_list=bufs, dst=dst, group=group, async_op=async_op)
+
+    def finish():
+        if async_op and work is not None:
+            work.wait()
+        if rank != dst:
+            return None
+        parts = [fmt.unpack(bufs[r][: counts[r]]) for r in range(world)]
+        res = torch.cat([p[0] for p in parts])
+        st = torch.cat([p[1] for p in parts]) if fmt.with_start else None
+        en = torch.cat([p[2] for p in parts])
+        return res, st, en
+
+    return finish
+
+
+class FinalGather:
+    """bench.py helper: remembers the last step's outputs and gathers them once at the end
+    (the north-star's "RCCL over xGMI only for the final result gather")."""
+
+    def __init__(self, max_result: int, line_len: int, with_start: bool):
+        self.max_result, self.line_len, self.with_start = max_result, line_len, with_start
+        self.last = None
+        self.gathered = None
+
+    def push(self, outputs):
+        self.last = outputs
+
+    def flush(self):
+        if self.last is None:
+            return None
+        r, s, e = self.last
+        fin = gather_outcomes(r, s if self.with_start else None, e,
+                              max_result=self.max_result, max_line_len=self.line_len)
+        self.gathered = fin()
+        return self.gathered

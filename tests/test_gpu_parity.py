@@ -100,7 +100,8 @@ def _fixed_inputs(name, n, stride, seed):
 
 
 @pytest.mark.parametrize("stride,n", [(64, 5000), (16, 1500), (4096, 300), (48, 2049),
-                                      (64, 1024 * 4 * 3 + 17)])
+                                      (64, 1024 * 4 * 3 + 17), (128, 3000), (192, 1111),
+                                      (64, 1), (64, 2047), (64, 2049)])
 @pytest.mark.parametrize("name", ["syn256", "uri", "err", "num3", "newyork", "dotstar_err"])
 def test_fixed_stride_hot_path_vs_oracle(name, stride, n):
     """The specialised fixed-stride kernels (k_fixed) against the oracle, all styles, check and
@@ -122,6 +123,9 @@ def test_fixed_stride_hot_path_vs_oracle(name, stride, n):
             assert np.array_equal(one_amd.check_batch(exe, data, si, lead, stride=stride, n=n), cr)
     if exe.info["fast_path"]:
         one_amd.match_batch(exe, data, 4, 0, stride=stride, n=n)
+        want = "k_stream" if stride % 64 == 0 else "k_fixed"
+        assert one_amd.last_kernel().startswith(want), one_amd.last_kernel()
+        one_amd.match_batch(exe, data, 1, 0, stride=stride, n=n)
         assert one_amd.last_kernel().startswith("k_fixed"), one_amd.last_kernel()
 
 

@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--no-start", action="store_true", help="outputs result + end only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--streams", type=int, default=1,
+    ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the steps are issued on round-robin (independent batches "
                          "overlap: one step's ramp-up hides under the previous step's tail)")
     return ap.parse_args()
@@ -115,11 +115,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    backend = os.environ.get("BENCH_BACKEND", "nccl")  # "gloo": single-GPU rehearsal of N > 1
+    if backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     with open(os.path.join(ROOT, "tests", "golden", "dfas", args.dfa + ".reda"), "rb") as f:
         blob = f.read()
@@ -141,17 +147,31 @@ def main():
                      torch.empty(n, dtype=torch.int64, device="cuda") if want_start else None,
                      torch.empty(n, dtype=torch.int64, device="cuda")))
 
+    # The timed loop calls the C-ABI entry point directly (redgpu_match_batch_dev) with argument
+    # tuples built once: at ~20 us per kernel the Python conveniences of one_amd.match_batch
+    # (tensor checks, allocation) would make the loop host-bound.
+    from one_amd import _lib
+    fn = _lib.lib().redgpu_match_batch_dev
+    cur_stream = torch.cuda.current_stream().cuda_stream
+    period = len(bufs) * nout * max(1, args.streams)
+    calls = []
+    for i in range(period):
+        r_, s_, e_ = outs[i % nout]
+        st = streams[i % len(streams)].cuda_stream if streams else cur_stream
+        calls.append((exe._h, int(one_amd.styLast), 0, bufs[i % len(bufs)].data_ptr(), None, L, n,
+                      r_.data_ptr(), s_.data_ptr() if s_ is not None else None, e_.data_ptr(),
+                      st))
+
     def step(i):
-        if streams is None:
-            return one_amd.match_batch(exe, bufs[i % len(bufs)], one_amd.styLast, False,
-                                       stride=L, n=n, want_start=want_start, out=outs[i % nout])
-        with torch.cuda.stream(streams[i % len(streams)]):
-            return one_amd.match_batch(exe, bufs[i % len(bufs)], one_amd.styLast, False,
-                                       stride=L, n=n, want_start=want_start, out=outs[i % nout])
+        rc = fn(*calls[i % period])
+        if rc != 0:
+            raise RuntimeError(_lib.lib().redgpu_last_error().decode())
+        return outs[i % nout]
 
     # ---- correctness gate: buffer 0 bit-exact against the CPU oracle ------------------------
     import oracle
-    r, s, e = step(0)
+    r, s, e = one_amd.match_batch(exe, bufs[0], one_amd.styLast, False, stride=L, n=n,
+                                  want_start=want_start, out=outs[0])
     torch.cuda.synchronize()
     er, es, ee = oracle.CpuOracle(blob).batch("match", "last", 0, host0, stride=L, n=n,
                                               threads=os.cpu_count() or 1)
@@ -164,7 +184,8 @@ def main():
     gather = None
     if world > 1:
         from one_amd import sharding
-        gather = sharding.FinalGather(info["max_result"], L, want_start)
+        gather = sharding.FinalGather(info["max_result"], L, want_start,
+                                      via_host=(backend != "nccl"))
 
     for i in range(args.warmup):
         o = step(i)
@@ -198,7 +219,8 @@ def main():
     region_ms = ev0.elapsed_time(ev1)
 
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -227,6 +249,12 @@ def main():
     # is the conservative one we report as `achieved`.
     kernel_ms = back_to_back_ms if (world == 1 and args.streams == 1) else k_avg_ms
     achieved = bytes_per_step / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if world == 1 and args.dfa == "syn256" and want_start and os.path.exists(pmc_path):
+        # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same kernel and
+        # workload (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE; scripts/profile_gpu.sh)
+        traffic = json.load(open(pmc_path)).get("hbm_traffic_bytes_per_launch")
     line = {
         "metric": "GB/s input scanned (and Minput/s) for fixed DFA",
         "value": round(value, 2),
@@ -256,7 +284,7 @@ def main():
         "kernel": kernel_name,
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": bytes_per_step,
             "output_bytes_per_launch": out_bytes,
             "kernel_ms_back_to_back": round(back_to_back_ms, 5),

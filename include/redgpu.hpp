@@ -1,0 +1,227 @@
+// redgpu.hpp - C++ mirror of RED's matcher interface over the C-ABI of redgpu.h.
+//
+// Same names, argument meaning and error behaviour as the reference for the hot path
+// (citations relative to /root/reference/quol/red/):
+//   Executable        include/Executable.h:28-76   (validated serialized DFA; move-only)
+//   Style             include/Matcher.h:67-74
+//   Result / Outcome  include/Types.h:22, include/Outcome.h:32-51
+//   check/match/scan  include/Matcher.h:79-92 (run-time style, doLeader = true) and
+//                     :133-169 (template <Style, bool doLeader>)
+//   RedExcept*        include/Except.h:30-107
+// plus the batch forms (checkBatch / matchBatch / scanBatch) that replace the callers'
+// per-input loops (tools/bench.cpp:60-71, tools/thr_red.cpp:36-47).  Header-only; link with
+// one_amd/libredgpu.so.  Single-input calls are batches of one ON THE GPU - there is no CPU
+// matcher behind this header.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <string_view>
+#include <utility>
+#include <vector>
+
+#include "redgpu.h"
+
+namespace redgpu {
+
+typedef uint8_t Byte;
+typedef int32_t Result;
+
+enum Style {
+  styInvalid = 0,
+  styInstant = 1,
+  styFirst = 2,
+  styTangent = 3,
+  styLast = 4,
+  styFull = 5,
+};
+
+struct Outcome {
+  Result result_;
+  size_t start_;
+  size_t end_;
+  bool operator==(const Outcome &rhs) const {
+    return result_ == rhs.result_ && start_ == rhs.start_ && end_ == rhs.end_;
+  }
+  explicit operator bool() const { return result_ > 0; }
+  static Outcome fail() { return Outcome{0, 0, 0}; }
+};
+
+class RedExcept : public std::runtime_error { using std::runtime_error::runtime_error; };
+class RedExceptInternal : public RedExcept { using RedExcept::RedExcept; };
+class RedExceptUser : public RedExcept { using RedExcept::RedExcept; };
+class RedExceptLimit : public RedExcept { using RedExcept::RedExcept; };
+class RedExceptExec : public RedExceptInternal { using RedExceptInternal::RedExceptInternal; };
+class RedExceptApi : public RedExceptUser { using RedExceptUser::RedExceptUser; };
+class RedExceptHip : public RedExceptExec { using RedExceptExec::RedExceptExec; };  // new
+
+inline void throwOnError(int rc) {
+  if (rc == REDGPU_OK) return;
+  const std::string msg = redgpu_last_error();
+  switch (rc) {
+  case REDGPU_EAPI: throw RedExceptApi(msg);
+  case REDGPU_EEXEC: throw RedExceptExec(msg);
+  case REDGPU_ELIMIT: throw RedExceptLimit(msg);
+  case REDGPU_EHIP: throw RedExceptHip(msg);
+  default: throw RedExcept(msg);
+  }
+}
+
+// tag types kept for source compatibility (include/Types.h:43-53); every constructor COPIES
+struct CopyTag {};
+constexpr CopyTag gCopyTag;
+struct UnownedTag {};
+constexpr UnownedTag gUnownedTag;
+
+class Executable {
+public:
+  Executable() : h_(nullptr) {}
+  Executable(Executable &&other) : h_(std::exchange(other.h_, nullptr)) {}
+  explicit Executable(std::string &&buf, int device = REDGPU_DEVICE_CURRENT) : h_(nullptr) {
+    if (buf.empty()) throw RedExceptApi("serialized dfa move-string is empty");
+    init(buf.data(), buf.size(), device);
+  }
+  Executable(const CopyTag &, std::string_view sv, int device = REDGPU_DEVICE_CURRENT)
+      : h_(nullptr) {
+    if (sv.empty()) throw RedExceptApi("serialized dfa string_view is empty");
+    init(sv.data(), sv.size(), device);
+  }
+  Executable(const UnownedTag &, std::string_view sv, int device = REDGPU_DEVICE_CURRENT)
+      : h_(nullptr) {
+    if (!sv.data()) throw RedExceptApi("serialized dfa unowned-view is empty");
+    init(sv.data(), sv.size(), device);
+  }
+  ~Executable() { redgpu_dfa_destroy(h_); }
+  Executable &operator=(Executable &&rhs) {
+    if (this != &rhs) {
+      redgpu_dfa_destroy(h_);
+      h_ = std::exchange(rhs.h_, nullptr);
+    }
+    return *this;
+  }
+  Executable(const Executable &) = delete;
+  Executable &operator=(const Executable &) = delete;
+
+  std::string_view serialized() const {
+    const void *p = nullptr;
+    size_t n = 0;
+    throwOnError(redgpu_dfa_serialized(h_, &p, &n));
+    return std::string_view(static_cast<const char *>(p), n);
+  }
+  redgpu_info info() const {
+    redgpu_info i;
+    throwOnError(redgpu_dfa_info(h_, &i));
+    return i;
+  }
+  const redgpu_dfa *handle() const { return h_; }
+
+private:
+  void init(const void *p, size_t n, int device) {
+    redgpu_opts o{};
+    o.device = device;
+    throwOnError(redgpu_dfa_create(p, n, &o, &h_));
+  }
+  redgpu_dfa *h_;
+};
+
+// ---- batch forms: line i = data[offsets[i], offsets[i+1]) (offsets has n+1 entries), or with
+// offsets == nullptr, data[i*stride, (i+1)*stride).  Host buffers. -----------------------------
+template <Style style, bool doLeader>
+void checkBatch(const Executable &exec, const Byte *data, const uint64_t *offsets, uint64_t stride,
+                uint64_t n, Result *result) {
+  throwOnError(redgpu_check_batch(exec.handle(), style, doLeader, data, offsets, stride, n, result));
+}
+
+template <Style style, bool doLeader>
+void matchBatch(const Executable &exec, const Byte *data, const uint64_t *offsets, uint64_t stride,
+                uint64_t n, Result *result, uint64_t *start, uint64_t *end) {
+  throwOnError(redgpu_match_batch(exec.handle(), style, doLeader, data, offsets, stride, n, result,
+                                  start, end));
+}
+
+template <Style style, bool doLeader>
+void scanBatch(const Executable &exec, const Byte *data, const uint64_t *offsets, uint64_t stride,
+               uint64_t n, Result *result) {
+  throwOnError(redgpu_scan_batch(exec.handle(), style, doLeader, data, offsets, stride, n, result));
+}
+
+inline std::vector<Outcome> matchBatch(const Executable &exec, const std::vector<std::string_view> &lines,
+                                       Style style, bool doLeader = true) {
+  std::string flat;
+  std::vector<uint64_t> off(lines.size() + 1, 0);
+  for (size_t i = 0; i < lines.size(); ++i) {
+    flat.append(lines[i]);
+    off[i + 1] = flat.size();
+  }
+  std::vector<Result> r(lines.size());
+  std::vector<uint64_t> s(lines.size()), e(lines.size());
+  throwOnError(redgpu_match_batch(exec.handle(), style, doLeader,
+                                  reinterpret_cast<const Byte *>(flat.data()), off.data(), 0,
+                                  lines.size(), r.data(), s.data(), e.data()));
+  std::vector<Outcome> out(lines.size());
+  for (size_t i = 0; i < lines.size(); ++i) out[i] = Outcome{r[i], size_t(s[i]), size_t(e[i])};
+  return out;
+}
+
+// ---- single-input forms with the reference's signatures (a batch of one on the GPU) ---------
+namespace detail {
+inline Result one(int (*fn)(const redgpu_dfa *, int, int, const uint8_t *, const uint64_t *,
+                            uint64_t, uint64_t, int32_t *),
+                  const Executable &exec, const void *ptr, size_t len, int style, bool lead) {
+  const uint64_t off[2] = {0, len};
+  Result r = 0;
+  throwOnError(fn(exec.handle(), style, lead, static_cast<const Byte *>(ptr), off, 0, 1, &r));
+  return r;
+}
+} // namespace detail
+
+template <Style style, bool doLeader>
+Result check(const Executable &exec, const void *ptr, size_t len) {
+  return detail::one(redgpu_check_batch, exec, ptr, len, style, doLeader);
+}
+template <Style style, bool doLeader>
+Result check(const Executable &exec, std::string_view sv) {
+  return check<style, doLeader>(exec, sv.data(), sv.size());
+}
+template <Style style, bool doLeader>
+Result scan(const Executable &exec, const void *ptr, size_t len) {
+  return detail::one(redgpu_scan_batch, exec, ptr, len, style, doLeader);
+}
+template <Style style, bool doLeader>
+Result scan(const Executable &exec, std::string_view sv) {
+  return scan<style, doLeader>(exec, sv.data(), sv.size());
+}
+template <Style style, bool doLeader>
+Outcome match(const Executable &exec, const void *ptr, size_t len) {
+  const uint64_t off[2] = {0, len};
+  Result r = 0;
+  uint64_t s = 0, e = 0;
+  throwOnError(redgpu_match_batch(exec.handle(), style, doLeader, static_cast<const Byte *>(ptr),
+                                  off, 0, 1, &r, &s, &e));
+  return Outcome{r, size_t(s), size_t(e)};
+}
+template <Style style, bool doLeader>
+Outcome match(const Executable &exec, std::string_view sv) {
+  return match<style, doLeader>(exec, sv.data(), sv.size());
+}
+
+// run-time style: doLeader = true, unknown style -> RedExceptExec("unsupported style")
+// (lib/Matcher.cpp:37-67)
+inline Result check(const Executable &exec, std::string_view sv, Style style) {
+  return detail::one(redgpu_check_batch, exec, sv.data(), sv.size(), style, true);
+}
+inline Result scan(const Executable &exec, std::string_view sv, Style style) {
+  return detail::one(redgpu_scan_batch, exec, sv.data(), sv.size(), style, true);
+}
+inline Outcome match(const Executable &exec, std::string_view sv, Style style) {
+  const uint64_t off[2] = {0, sv.size()};
+  Result r = 0;
+  uint64_t s = 0, e = 0;
+  throwOnError(redgpu_match_batch(exec.handle(), style, 1,
+                                  reinterpret_cast<const Byte *>(sv.data()), off, 0, 1, &r, &s, &e));
+  return Outcome{r, size_t(s), size_t(e)};
+}
+
+} // namespace redgpu

@@ -5,10 +5,12 @@
 // at LDS offset 0), styles Last and Full of check / match (include/Matcher.h:363-495).
 //
 // Shape, and why (every number below was measured on MI355X, tools/tune.hip):
-//  * One workgroup of 1024 threads per CU shares one table copy; staging it costs ~1.6 us and is
+//  * One workgroup of 512 threads per CU shares one table copy (8 waves x 2 lines = 16 dependent
+//    chains per CU; 1024 threads saturate the LDS better in steady state but need twice the
+//    data before their first step - on 64 MiB batches 512 wins); staging it costs ~1.6 us and is
 //    done BEFORE any input is requested - input requests issued earlier sit in front of the
 //    table's in the CU's memory queues and delay the table barrier to ~6 us.
-//  * Each lane walks 2 lines at once (two dependent chains per lane, 32 wave-chains per CU).
+//  * Each lane walks 2 lines at once (two dependent chains per lane).
 //    Per line a ring of four 16-byte pieces lives in VGPRs; while piece p is walked, piece p+3
 //    is requested into the slot piece p-1 vacated.  All requests are unconditional so the
 //    compiler's in-order vmcnt counts are exact (a conditional request made it fall back to
@@ -23,7 +25,7 @@
 //    ~9 bytes/clk/CU: the LDS gather rate, not HBM, is this kernel's roof.
 #pragma once
 
-constexpr int kStreamThreads = 1024;
+constexpr int kStreamThreads = 512;
 constexpr int kStreamChains = 2;
 constexpr uint32_t kStreamTabBytes = 65536;
 

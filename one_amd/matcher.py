@@ -90,11 +90,15 @@ class Executable:
         _check(_lib.lib().redgpu_dfa_create(blob, len(blob), C.byref(o), C.byref(self._h)))
 
     def close(self):
-        if getattr(self, "_h", None):
-            _lib.lib().redgpu_dfa_destroy(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None and getattr(_lib, "_lib", None) is not None:
+            _lib._lib.redgpu_dfa_destroy(h)  # (at interpreter exit the module may be gone)
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     @property
     def info(self) -> dict:

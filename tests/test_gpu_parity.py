@@ -237,3 +237,20 @@ def test_full_size_config2_bit_exact():
         r1 = one_amd.match_batch(exe, data[:h * stride], 4, 0, stride=stride, n=h)[0]
         r2 = one_amd.match_batch(exe, data[h * stride:], 4, 0, stride=stride, n=h)[0]
         assert np.array_equal(np.concatenate([r1, r2]), r)
+
+
+def test_cpp_mirror_through_cabi(tmp_path):
+    """include/redgpu.hpp (the C++ mirror of the reference's names) compiled with g++ and run
+    against the golden blobs: the reference's tests, re-read through the C-ABI."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "matcher_cabi_test")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "cpp", "matcher_cabi_test.cpp"), "-o", exe,
+                    "-L", os.path.join(root, "one_amd"), "-lredgpu",
+                    "-Wl,-rpath," + os.path.join(root, "one_amd")], check=True)
+    out = subprocess.run([exe, os.path.join(root, "tests", "golden", "dfas")],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all C++ mirror checks passed" in out.stdout

@@ -10,11 +10,10 @@
 //    data before their first step - on 64 MiB batches 512 wins); staging it costs ~1.6 us and is
 //    done BEFORE any input is requested - input requests issued earlier sit in front of the
 //    table's in the CU's memory queues and delay the table barrier to ~6 us.
-//  * Each lane walks 2 lines at once (two dependent chains per lane).
-//    Per line a ring of four 16-byte pieces lives in VGPRs; while piece p is walked, piece p+3
-//    is requested into the slot piece p-1 vacated.  All requests are unconditional so the
-//    compiler's in-order vmcnt counts are exact (a conditional request made it fall back to
-//    vmcnt(0), which serialised every fourth piece behind a full HBM round trip).
+//  * Each lane walks 2 lines at once (two dependent chains per lane).  Input blocks are
+//    requested unconditionally (past the end of the work the last block is re-read) so the
+//    compiler's in-order vmcnt counts stay exact - a conditional request made it fall back to
+//    vmcnt(0), which serialised the walk behind a full HBM round trip.
 //  * The byte step is inline asm: first the dependent chain for both lines
 //    (v_perm_b32 forms (state << 8) | byte, ds_read_u8 fetches the next state), then the
 //    previous state's bookkeeping under the LDS latency, then one s_waitcnt lgkmcnt(0).
@@ -120,21 +119,35 @@ __device__ __forceinline__ void streamWalk16(const uint4 (&piece)[2], uint32_t (
 #undef RS_WORD
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(kStreamThreads)
+// =========================================================================================
+// k_stream<MODE, HALVES>: each lane pulls a whole block of its line - 128 bytes (HALVES = 2,
+// stride % 128 == 0: one full cache line) or 64 bytes (HALVES = 1) - with back-to-back 16-byte
+// loads (the first misses, the rest hit the line in L1) into one of two register sets
+// (ping-pong: the next block streams in while this one is walked).  2 lines per lane, 512
+// threads, up to 128 data VGPRs.  A 16-byte "piece ring" (request piece p+3 while walking p)
+// needs a quarter of the registers but touches every cache line 4-8 times: 2.6 TB/s at 4 KiB
+// lines against 4.2 TB/s for this form, and no faster at 64 B either.
+// =========================================================================================
+template <int HALVES>
+struct BlockRegs {
+  uint4 p[4 * HALVES];
+};
+
+// HALVES = 2: 128-byte blocks (stride % 128 == 0); HALVES = 1: 64-byte blocks (stride % 64 == 0)
+template <int MODE, int HALVES, int THREADS>
+__global__ void __launch_bounds__(THREADS)
 k_stream(DevDfa d, Batch io) {
+  constexpr uint32_t BLK = 64 * HALVES;
   constexpr int CH = kStreamChains;
-  constexpr int THREADS = kStreamThreads;
   constexpr bool kAcc = MODE == kSmLastStartEnd || MODE == kSmLastEnd;
   constexpr bool kStart = MODE == kSmLastStartEnd || MODE == kSmFullStart;
-  // the kernel's only LDS object: the table MUST sit at LDS offset 0 (asm addresses it so)
-  __shared__ __align__(16) uint8_t lds[kStreamTabBytes + 1024];
+  __shared__ __align__(16) uint8_t lds[kStreamTabBytes + 1024];  // table at LDS offset 0
   uint8_t *tab = lds;
   int32_t *ldsRes = reinterpret_cast<int32_t *>(lds + kStreamTabBytes);
 
   const uint32_t init = d.init, firstAccept = d.firstAccept;
   const uint32_t lineLen = uint32_t(io.stride);
-  const uint32_t R = lineLen / 64;  // 64-byte blocks per line
+  const uint32_t R = lineLen / BLK;  // blocks per line
   const uint64_t linesPerTile = uint64_t(THREADS) * CH;
   const uint64_t nTiles = (io.n + linesPerTile - 1) / linesPerTile;
   const uint64_t G = gridDim.x;
@@ -142,14 +155,6 @@ k_stream(DevDfa d, Batch io) {
   const uint64_t myTiles = (nTiles - blockIdx.x + G - 1) / G;
   const uint64_t Q = myTiles * R;
 
-  auto blockPtr = [&](uint64_t tile, uint32_t r, int c) {
-    uint64_t ln = tile * linesPerTile + uint64_t(c) * THREADS + threadIdx.x;
-    if (ln >= io.n) ln = io.n - 1;  // surplus lanes re-walk the last line; nothing is stored
-    return io.data + ln * lineLen + r * 64;
-  };
-  auto ld = [](const uint8_t *p, int k) { return reinterpret_cast<const uint4 *>(p)[k]; };
-
-  // ---- table first: 4 coalesced 16-byte pieces per thread (+ the result codes) ------------
   {
     const uint4 *src = reinterpret_cast<const uint4 *>(d.table);
     const uint32_t n16 = d.tableBytes / 16;
@@ -167,29 +172,40 @@ k_stream(DevDfa d, Batch io) {
   }
   __syncthreads();
 
-  uint4 slot[4][CH];
-  const uint8_t *cur[CH], *nxt[CH];
-  uint64_t tile = blockIdx.x;
-  uint32_t r = 0;
+  // load cursor (runs one block ahead of the walk cursor)
+  uint64_t ldTile = blockIdx.x;
+  uint32_t ldR = 0;
+  uint64_t ldQ = 0;
+  auto issue = [&](BlockRegs<HALVES> (&b)[CH]) {
+    // past the end of the work: re-read the last block (keeps requests unconditional)
+    const uint64_t t = ldQ < Q ? ldTile : ldTile - (ldR == 0 ? G : 0);
+    const uint32_t rr = ldQ < Q ? ldR : (ldR == 0 ? R - 1 : ldR - 1);
+    const uint8_t *p[CH];
 #pragma unroll
-  for (int c = 0; c < CH; ++c) cur[c] = blockPtr(tile, 0, c);
+    for (int c = 0; c < CH; ++c) {
+      uint64_t ln = t * linesPerTile + uint64_t(c) * THREADS + threadIdx.x;
+      if (ln >= io.n) ln = io.n - 1;
+      p[c] = io.data + ln * lineLen + uint64_t(rr) * BLK;
+    }
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 4 * HALVES; ++k) {
 #pragma unroll
-    for (int c = 0; c < CH; ++c) slot[k][c] = ld(cur[c], k);
-  }
+      for (int c = 0; c < CH; ++c) b[c].p[k] = reinterpret_cast<const uint4 *>(p[c])[k];
+    }
+    if (ldQ < Q) {
+      ++ldQ;
+      if (++ldR == R) { ldR = 0; ldTile += G; }
+    }
+  };
 
   uint32_t s[CH], accS[CH], endv[CH], startv[CH];
   uint64_t mA[CH], mB[CH];
-  for (uint64_t q = 0; q < Q; ++q) {
-    // where each chain's NEXT 64-byte block lives: further along the same lines, or the next
-    // tile's lines; past the end of the work it is this block again (harmless re-read)
-    const bool haveNext = q + 1 < Q;
-    uint32_t nr = r + 1;
-    uint64_t ntile = tile;
-    if (nr == R) { nr = 0; ntile = tile + G; }
-#pragma unroll
-    for (int c = 0; c < CH; ++c) nxt[c] = blockPtr(haveNext ? ntile : tile, haveNext ? nr : r, c);
+  uint64_t tile = blockIdx.x;
+  uint32_t r = 0;
+
+  // walk one 128-byte block held in registers: two 64-byte halves, each folded on its own so
+  // the block-relative positions stay inline constants (0..63)
+  auto walkBlock = [&](const BlockRegs<HALVES> (&blk)[CH]) {
     if (r == 0) {
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
@@ -197,40 +213,37 @@ k_stream(DevDfa d, Batch io) {
         mA[c] = ~0ull; mB[c] = ~0ull;
       }
     }
-    StreamBook b[CH];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) { b[c].acc = accS[c]; b[c].end = 0; b[c].start = 0; }
-
+    for (int h = 0; h < HALVES; ++h) {
+      StreamBook b[CH];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) slot[3][c] = ld(cur[c], 3);
-    streamWalk16<MODE, 0>(slot[0], s, b, mA, mB, firstAccept, init);
+      for (int c = 0; c < CH; ++c) { b[c].acc = accS[c]; b[c].end = 0; b[c].start = 0; }
+      uint4 piece[CH];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) slot[0][c] = ld(nxt[c], 0);
-    streamWalk16<MODE, 1>(slot[1], s, b, mA, mB, firstAccept, init);
+      for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[4 * h + 0];
+      streamWalk16<MODE, 0>(piece, s, b, mA, mB, firstAccept, init);
 #pragma unroll
-    for (int c = 0; c < CH; ++c) slot[1][c] = ld(nxt[c], 1);
-    streamWalk16<MODE, 2>(slot[2], s, b, mA, mB, firstAccept, init);
+      for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[4 * h + 1];
+      streamWalk16<MODE, 1>(piece, s, b, mA, mB, firstAccept, init);
 #pragma unroll
-    for (int c = 0; c < CH; ++c) slot[2][c] = ld(nxt[c], 2);
-    streamWalk16<MODE, 3>(slot[3], s, b, mA, mB, firstAccept, init);
-
-    // Fold the block-relative events into absolute positions.  A recorded relative index k
-    // (1..63) is "the state after k bytes": matchEnd = off + k (Matcher.h:463), matchStart =
-    // off + k - 1 (the byte that left the initial state, Matcher.h:446-451).  Index 0 is the
-    // carried-in state, already accounted for at the end of the previous block.  The state
-    // after this block's 64th byte is handled here, once per block, in plain code.
-    const uint32_t off = r * 64;
+      for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[4 * h + 2];
+      streamWalk16<MODE, 2>(piece, s, b, mA, mB, firstAccept, init);
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      if (kAcc) {
-        accS[c] = b[c].acc;
-        endv[c] = b[c].end ? off + b[c].end : endv[c];
-        if (s[c] >= firstAccept) { accS[c] = s[c]; endv[c] = off + 64; }
-      }
-      if (kStart) {
-        startv[c] = b[c].start ? off + b[c].start - 1 : startv[c];
-        const bool wasInit63 = (mA[c] >> (threadIdx.x & 63)) & 1;  // written by the last step
-        if (wasInit63 && s[c] != init) startv[c] = off + 63;
+      for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[4 * h + 3];
+      streamWalk16<MODE, 3>(piece, s, b, mA, mB, firstAccept, init);
+      const uint32_t off = r * BLK + h * 64;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        if (kAcc) {
+          accS[c] = b[c].acc;
+          endv[c] = b[c].end ? off + b[c].end : endv[c];
+          if (s[c] >= firstAccept) { accS[c] = s[c]; endv[c] = off + 64; }
+        }
+        if (kStart) {
+          startv[c] = b[c].start ? off + b[c].start - 1 : startv[c];
+          const bool wasInit63 = (mA[c] >> (threadIdx.x & 63)) & 1;
+          if (wasInit63 && s[c] != init) startv[c] = off + 63;
+        }
       }
     }
     if (++r == R) {
@@ -242,12 +255,10 @@ k_stream(DevDfa d, Batch io) {
           int32_t rr;
           uint32_t en;
           if (kAcc) {
-            // endv != 0 <=> an accepting state was REACHED (an accepting initial state alone
-            // does not count for non-empty input, Matcher.h:443-468)
             rr = endv[c] ? ldsRes[accS[c]] : 0;
             en = endv[c];
           } else {
-            rr = s[c] >= firstAccept ? ldsRes[s[c]] : 0;  // styFull: the final state's result
+            rr = s[c] >= firstAccept ? ldsRes[s[c]] : 0;
             en = lineLen;
           }
           io.result[ln] = rr;
@@ -257,33 +268,42 @@ k_stream(DevDfa d, Batch io) {
       }
       tile += G;
     }
-#pragma unroll
-    for (int c = 0; c < CH; ++c) cur[c] = nxt[c];
+  };
+
+  BlockRegs<HALVES> A[CH], B[CH];
+  issue(A);
+  for (uint64_t q = 0; q < Q; q += 2) {
+    issue(B);
+    walkBlock(A);
+    issue(A);
+    if (q + 1 < Q) walkBlock(B);
   }
 }
 
-#undef RS_PERM
-#undef RS_READ
-#undef RS_CMPA
-#undef RS_CMPI
-#undef RS_ACC
-#undef RS_END
-#undef RS_LEAVE
-#undef RS_START
-#undef RS_WAIT
-#undef RS_O_CHAIN
-#undef RS_O_ACC
-#undef RS_O_END
-#undef RS_O_START
-#undef RS_I_CHAIN
-#undef RS_I_START
+template <int MODE, int THREADS>
+hipError_t launchStreamTT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
+                          hipStream_t stream) {
+  const uint64_t linesPerTile = uint64_t(THREADS) * kStreamChains;
+  const uint64_t tiles = (b.n + linesPerTile - 1) / linesPerTile;
+  const uint64_t blocks = tiles < uint64_t(cfg.numCUs) ? tiles : uint64_t(cfg.numCUs);
+  if (b.stride % 128 == 0)
+    hipLaunchKernelGGL((k_stream<MODE, 2, THREADS>), dim3(uint32_t(blocks)), dim3(THREADS), 0,
+                       stream, d, b);
+  else
+    hipLaunchKernelGGL((k_stream<MODE, 1, THREADS>), dim3(uint32_t(blocks)), dim3(THREADS), 0,
+                       stream, d, b);
+  return hipGetLastError();
+}
 
 template <int MODE>
 hipError_t launchStreamT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
                          hipStream_t stream) {
-  const uint64_t linesPerTile = uint64_t(kStreamThreads) * kStreamChains;
-  const uint64_t tiles = (b.n + linesPerTile - 1) / linesPerTile;
-  const uint64_t blocks = tiles < uint64_t(cfg.numCUs) ? tiles : uint64_t(cfg.numCUs);
-  hipLaunchKernelGGL(k_stream<MODE>, dim3(uint32_t(blocks)), dim3(kStreamThreads), 0, stream, d, b);
-  return hipGetLastError();
+  static const int threads = [] {
+    const char *e = getenv("REDGPU_STREAM_THREADS");  // tuning knob; default 512
+    const int v = e ? atoi(e) : kStreamThreads;
+    return (v == 256 || v == 1024) ? v : 512;
+  }();
+  if (threads == 256) return launchStreamTT<MODE, 256>(d, b, cfg, stream);
+  if (threads == 1024) return launchStreamTT<MODE, 1024>(d, b, cfg, stream);
+  return launchStreamTT<MODE, 512>(d, b, cfg, stream);
 }

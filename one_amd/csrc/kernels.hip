@@ -18,6 +18,8 @@
 //                     gather workload bounded by HBM input streaming and the LDS gather rate.
 #include "kernels.h"
 
+#include <cstdlib>
+
 #include "../../include/redgpu.h"
 
 namespace redgpu {

@@ -74,7 +74,11 @@ def cpu_baseline(args, blob, host_batch):
     its prebuilt .so travelled with the repo, else the C restatement; all host cores, one
     contiguous shard per thread as tools/thr_red.cpp:86-91 does.  Bounded to ~cpu_seconds."""
     import oracle
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))  # the box's CPU share, not the machine's
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
     if oracle.have_ref():
         eng, kind = oracle.Reference(blob), "reference"
     else:

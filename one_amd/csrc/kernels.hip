@@ -121,6 +121,35 @@ __device__ __forceinline__ bool compareThrough(const LaneCtx &c, const uint8_t *
   return true;
 }
 
+// Feeds f(byte, index) the bytes p[from..n) in order until it returns false.  The body reads
+// 16-byte aligned chunks (one global_load_dwordx4 per 16 input bytes instead of 16 byte loads);
+// the unaligned head and the tail go byte by byte.
+template <class F>
+__device__ __forceinline__ void walkBytes(const uint8_t *p, uint64_t from, uint64_t n, F &&f) {
+  uint64_t i = from;
+  const uint32_t mis = uint32_t(reinterpret_cast<uintptr_t>(p + i)) & 15u;
+  if (mis) {
+    uint64_t headEnd = i + (16 - mis);
+    if (headEnd > n) headEnd = n;
+    for (; i < headEnd; ++i)
+      if (!f(uint32_t(p[i]), i)) return;
+  }
+  for (; i + 16 <= n; i += 16) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(p + i);
+    // words rolled, bytes unrolled: keeps the body (and its registers) small - these kernels
+    // are latency-bound and live on occupancy
+#pragma unroll 1
+    for (int wi = 0; wi < 4; ++wi) {
+      const uint32_t word = wi == 0 ? v.x : wi == 1 ? v.y : wi == 2 ? v.z : v.w;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (!f((word >> (8 * k)) & 0xffu, i + 4 * wi + k)) return;
+    }
+  }
+  for (; i < n; ++i)
+    if (!f(uint32_t(p[i]), i)) return;
+}
+
 // include/Matcher.h:363-410
 template <class T>
 __device__ int32_t checkLane(const T &tab, const LaneCtx &c, const uint8_t *p, uint64_t n,
@@ -134,22 +163,28 @@ __device__ int32_t checkLane(const T &tab, const LaneCtx &c, const uint8_t *p, u
     s = c.init;
   int32_t result = c.resultOf(s);
   int32_t prev = 0;
-  for (; i < n; ++i) {
-    s = tab.next(s, p[i]);
+  bool returned = false;
+  int32_t retval = 0;
+  walkBytes(p, i, n, [&](uint32_t byte, uint64_t) {
+    s = tab.next(s, byte);
     if (s >= c.firstAccept) {
       result = c.res[s];
-      if (style == kStyInstant) return result;
+      if (style == kStyInstant) { returned = true; retval = result; return false; }
       if (style == kStyFirst) {
-        if (prev && result != prev) return prev;
+        if (prev && result != prev) { returned = true; retval = prev; return false; }
         prev = result;
       }
       if (style == kStyTangent || style == kStyLast) prev = result;
     } else {
       result = 0;
-      if ((style == kStyFirst || style == kStyTangent) && prev > 0) return prev;
-      if (s < c.nPureDead) break;
+      if ((style == kStyFirst || style == kStyTangent) && prev > 0) {
+        returned = true; retval = prev; return false;
+      }
+      if (s < c.nPureDead) return false;
     }
-  }
+    return true;
+  });
+  if (returned) return retval;
   if (style == kStyLast && result == 0 && prev > 0) return prev;
   return result;
 }
@@ -165,26 +200,27 @@ __device__ int32_t matchLane(const T &tab, const LaneCtx &c, const uint8_t *p, u
   int32_t result = c.resultOf(s);
   int32_t prev = 0;
   uint64_t matchStart = 0, matchEnd = 0;
-  for (uint64_t idx = 0; idx < n; ++idx) {
+  walkBytes(p, 0, n, [&](uint32_t byte, uint64_t idx) {
     const uint32_t was = s;
-    s = tab.next(s, p[idx]);
+    s = tab.next(s, byte);
     if (was == c.init && s != was) matchStart = idx;  // "escaped the initial state" :446-451
     if (s >= c.firstAccept) {
       result = c.res[s];
       if (style == kStyFirst) {
-        if (prev && result != prev) { result = prev; break; }
+        if (prev && result != prev) { result = prev; return false; }
         prev = result;
       }
       matchEnd = idx + 1;
-      if (style == kStyInstant) break;
+      if (style == kStyInstant) return false;
       if (style == kStyTangent || style == kStyLast) prev = result;
     } else {
       result = 0;
-      if (style == kStyFirst && prev > 0) { result = prev; break; }
-      if (style == kStyTangent && prev > 0) break;
-      if (s < c.nPureDead) break;
+      if (style == kStyFirst && prev > 0) { result = prev; return false; }
+      if (style == kStyTangent && prev > 0) return false;
+      if (s < c.nPureDead) return false;
     }
-  }
+    return true;
+  });
   if ((style == kStyTangent || style == kStyLast) && result == 0 && prev > 0) result = prev;
   if (result != 0) {
     startOut = matchStart;
@@ -229,10 +265,9 @@ __device__ int32_t scanLane(const T &tab, const LaneCtx &c, const uint8_t *p, ui
   return result;
 }
 
-constexpr int kGenericThreads = 256;
-
-// dynamic LDS: [equiv 256][leader 256][table (LDS kinds only)]
-template <int KIND>
+// dynamic LDS: [equiv 256][leader 256][table (LDS kinds only)].  An LDS-resident table is
+// shared by one 1024-thread workgroup per CU; a table in HBM/L2 runs 256-thread workgroups.
+template <int KIND, int kGenericThreads>
 __global__ void __launch_bounds__(kGenericThreads)
 k_generic(DevDfa d, Batch b, int verb, int style, int lead) {
   extern __shared__ __align__(16) uint8_t lds[];
@@ -473,16 +508,18 @@ hipError_t setLds(K kernel, size_t bytes) {
 template <int KIND>
 hipError_t launchGeneric(const DevDfa &d, const Batch &b, int verb, int style, int lead,
                          const LaunchCfg &cfg, hipStream_t stream) {
+  constexpr int kThreads = Tab<KIND>::kInLds ? 1024 : 256;
   const size_t ldsBytes = 512 + (Tab<KIND>::kInLds ? size_t(d.tableBytes) : 0);
-  hipError_t e = setLds(k_generic<KIND>, ldsBytes);
+  hipError_t e = setLds(k_generic<KIND, kThreads>, ldsBytes);
   if (e != hipSuccess) return e;
-  uint64_t blocks = (b.n + kGenericThreads - 1) / kGenericThreads;
+  uint64_t blocks = (b.n + kThreads - 1) / kThreads;
   // an LDS-resident table is re-staged per block: keep the grid near one wave of blocks
-  const uint64_t cap = uint64_t(cfg.numCUs) * (Tab<KIND>::kInLds ? 2 : 8);
+  const uint64_t perCu = Tab<KIND>::kInLds ? (ldsBytes <= 80 * 1024 ? 2 : 1) : 8;
+  const uint64_t cap = uint64_t(cfg.numCUs) * perCu;
   if (blocks > cap) blocks = cap;
   if (blocks == 0) blocks = 1;
-  hipLaunchKernelGGL(k_generic<KIND>, dim3(uint32_t(blocks)), dim3(kGenericThreads), ldsBytes,
-                     stream, d, b, verb, style, lead);
+  hipLaunchKernelGGL((k_generic<KIND, kThreads>), dim3(uint32_t(blocks)), dim3(kThreads),
+                     ldsBytes, stream, d, b, verb, style, lead);
   return hipGetLastError();
 }
 

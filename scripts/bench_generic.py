@@ -1,0 +1,39 @@
+"""Throughput of the not-yet-tuned paths: ragged lines (k_generic), big DFAs (table in HBM/L2)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch, one_amd
+from one_amd import workloads as W
+from golden_util import load_dfa
+from oracle.reda_writer import random_dfa
+
+def timeit(fn, total_bytes, label, it=10):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(it): fn()
+    b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / it
+    print("%-62s %9.1f us %8.1f GB/s  %s" % (label, ms * 1e3, total_bytes / ms / 1e6, one_amd.last_kernel()), flush=True)
+
+# config 4: LOG-100, ragged 32..256 B
+n = 1 << 20
+data, offsets = W.ragged_lines(n, 32, 256, 4, heads=W.log100_heads(), head_every=2)
+d = torch.from_numpy(data).cuda(); o = torch.from_numpy(offsets.astype(np.int64)).cuda()
+exe = one_amd.Executable(load_dfa("log100"))
+timeit(lambda: one_amd.match_batch(exe, d, 4, 1, offsets=o), data.size, "config4: LOG-100 (3150 st) 2^20 ragged lines match<Last,true>")
+exe_u = one_amd.Executable(load_dfa("uri"))
+timeit(lambda: one_amd.match_batch(exe_u, d, 4, 0, offsets=o), data.size, "URI-D (LDS table) same ragged lines match<Last,false>")
+timeit(lambda: one_amd.scan_batch(exe_u, d, 1, 1, offsets=o), data.size, "URI-D scan<Instant,true> same ragged lines")
+exe_e = one_amd.Executable(load_dfa("err"))
+timeit(lambda: one_amd.scan_batch(exe_e, d, 1, 1, offsets=o), data.size, "ERR scan<Instant,true> same ragged lines (anchored, leader)")
+# config 5: 4K-state DFA, 64 KiB inputs
+blob = random_dfa(4097, 256, 5, accept_frac=0.1)
+exe5 = one_amd.Executable(blob)
+n5, L5 = 4096, 65536
+d5 = torch.randint(0, 256, (n5 * L5,), dtype=torch.uint8, device="cuda")
+timeit(lambda: one_amd.match_batch(exe5, d5, 4, 0, stride=L5, n=n5), n5 * L5, "config5: SYN-4K (2 MiB table in L2) 4096 x 64 KiB", it=3)
+n6, L6 = 1 << 18, 1024
+d6 = torch.randint(0, 256, (n6 * L6,), dtype=torch.uint8, device="cuda")
+timeit(lambda: one_amd.match_batch(exe5, d6, 4, 0, stride=L6, n=n6), n6 * L6, "SYN-4K 2^18 x 1 KiB", it=3)

@@ -254,3 +254,52 @@ def test_cpp_mirror_through_cabi(tmp_path):
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all C++ mirror checks passed" in out.stdout
+
+
+def test_config3_shape_4k_lines_vs_oracle():
+    """BASELINE configs[2] shape at reduced count: 4 KiB lines (k_stream, 128-byte blocks),
+    SYN-256 and URI-D, full Outcome, vs the oracle; plus the split/concatenate property."""
+    n, stride = 40000, 4096
+    for name in ("syn256", "uri"):
+        blob = load_dfa(name)
+        exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
+        data = (W.fixed_lines(n, stride, 3, alphabet=False) if name == "syn256" else
+                W.fixed_lines(n, stride, 3, plant=W.URI_PLANT, plant_at=1000))
+        for si in (4, 5):
+            r, s, e = one_amd.match_batch(exe, data, si, 0, stride=stride, n=n)
+            er, es, ee = cpu.batch("match", si, 0, data, stride=stride, n=n, threads=8)
+            assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee)
+        assert one_amd.last_kernel().startswith("k_stream")
+        h = 12345
+        r1 = one_amd.match_batch(exe, data[:h * stride], 4, 0, stride=stride, n=h)[0]
+        r2 = one_amd.match_batch(exe, data[h * stride:], 4, 0, stride=stride, n=n - h)[0]
+        assert np.array_equal(np.concatenate([r1, r2]), one_amd.match_batch(
+            exe, data, 4, 0, stride=stride, n=n)[0])
+
+
+def test_config4_shape_log100_ragged_vs_oracle():
+    """BASELINE configs[3] shape at reduced count: LOG-100 (3150 states, table in HBM/L2),
+    2^17 ragged lines of 32..256 B, matchLong = match<styLast,true>."""
+    n = 1 << 17
+    blob = load_dfa("log100")
+    exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
+    data, offsets = W.ragged_lines(n, 32, 256, 4, heads=W.log100_heads(), head_every=2)
+    r, s, e = one_amd.match_batch(exe, data, 4, 1, offsets=offsets)
+    er, es, ee = cpu.batch("match", 4, 1, data, offsets=offsets, threads=8)
+    assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee)
+    assert len(np.unique(er)) > 50  # many different signatures matched
+    assert np.array_equal(one_amd.check_batch(exe, data, 5, 1, offsets=offsets),
+                          cpu.batch("check", 5, 1, data, offsets=offsets, threads=8)[0])
+
+
+def test_config5_shape_4k_state_dfa_long_inputs_vs_oracle():
+    """BASELINE configs[4] shape at reduced count: ~4K-state / 256-class DFA (2 MiB table,
+    L2-resident gather), 64 KiB inputs."""
+    blob = random_dfa(4097, 256, 5, accept_frac=0.1)
+    exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
+    assert exe.info["table_kind"] in (4, 5)
+    n, stride = 512, 65536
+    data = W.fixed_lines(n, stride, 5, alphabet=False)
+    r, s, e = one_amd.match_batch(exe, data, 4, 0, stride=stride, n=n)
+    er, es, ee = cpu.batch("match", 4, 0, data, stride=stride, n=n, threads=8)
+    assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee)

@@ -123,6 +123,11 @@ int redgpu_match_batch(const redgpu_dfa *dfa, int style, int do_leader, const ui
                        uint64_t *start, uint64_t *end);
 int redgpu_scan_batch(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
                       const uint64_t *offsets, uint64_t stride, uint64_t n, int32_t *result);
+/*   redgpu_search_batch <-> search<style,doLeader>(exec, ptr, len) include/Matcher.h:172-173,557-640
+ *                           (scan with positions; the first of SURVEY 8(f)'s "next" rows) */
+int redgpu_search_batch(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                        const uint64_t *offsets, uint64_t stride, uint64_t n, int32_t *result,
+                        uint64_t *start, uint64_t *end);
 
 /* ---- the same verbs over DEVICE-resident buffers, asynchronous on `stream` ---------------
  * data/offsets/result/start/end are device pointers on the handle's device; `stream` is a
@@ -136,6 +141,9 @@ int redgpu_match_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, cons
 int redgpu_scan_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
                           const uint64_t *offsets, uint64_t stride, uint64_t n, int32_t *result,
                           void *stream);
+int redgpu_search_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                            const uint64_t *offsets, uint64_t stride, uint64_t n,
+                            int32_t *result, uint64_t *start, uint64_t *end, void *stream);
 
 /* Name of the kernel the last *_batch* call on this thread launched (for profiles), or "". */
 const char *redgpu_last_kernel(void);

@@ -207,6 +207,31 @@ Outcome match(const Executable &exec, std::string_view sv) {
   return match<style, doLeader>(exec, sv.data(), sv.size());
 }
 
+// search<style,doLeader>: include/Matcher.h:172-182,557-640 (sliding-window match)
+template <Style style, bool doLeader>
+Outcome search(const Executable &exec, std::string_view sv) {
+  const uint64_t off[2] = {0, sv.size()};
+  Result r = 0;
+  uint64_t s = 0, e = 0;
+  throwOnError(redgpu_search_batch(exec.handle(), style, doLeader,
+                                   reinterpret_cast<const Byte *>(sv.data()), off, 0, 1, &r, &s, &e));
+  return Outcome{r, size_t(s), size_t(e)};
+}
+inline Outcome search(const Executable &exec, std::string_view sv, Style style) {
+  const uint64_t off[2] = {0, sv.size()};
+  Result r = 0;
+  uint64_t s = 0, e = 0;
+  throwOnError(redgpu_search_batch(exec.handle(), style, 1,
+                                   reinterpret_cast<const Byte *>(sv.data()), off, 0, 1, &r, &s, &e));
+  return Outcome{r, size_t(s), size_t(e)};
+}
+template <Style style, bool doLeader>
+void searchBatch(const Executable &exec, const Byte *data, const uint64_t *offsets, uint64_t stride,
+                 uint64_t n, Result *result, uint64_t *start, uint64_t *end) {
+  throwOnError(redgpu_search_batch(exec.handle(), style, doLeader, data, offsets, stride, n, result,
+                                   start, end));
+}
+
 // run-time style: doLeader = true, unknown style -> RedExceptExec("unsupported style")
 // (lib/Matcher.cpp:37-67)
 inline Result check(const Executable &exec, std::string_view sv, Style style) {

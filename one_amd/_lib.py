@@ -88,14 +88,18 @@ def lib() -> C.CDLL:
             f = getattr(l, name)
             f.restype = C.c_int
             f.argtypes = [vp, i32, i32, vp, vp, u64, u64, vp]
-        l.redgpu_match_batch.restype = C.c_int
-        l.redgpu_match_batch.argtypes = [vp, i32, i32, vp, vp, u64, u64, vp, vp, vp]
+        for name in ("redgpu_match_batch", "redgpu_search_batch"):
+            f = getattr(l, name)
+            f.restype = C.c_int
+            f.argtypes = [vp, i32, i32, vp, vp, u64, u64, vp, vp, vp]
         for name in ("redgpu_check_batch_dev", "redgpu_scan_batch_dev"):
             f = getattr(l, name)
             f.restype = C.c_int
             f.argtypes = [vp, i32, i32, vp, vp, u64, u64, vp, vp]
-        l.redgpu_match_batch_dev.restype = C.c_int
-        l.redgpu_match_batch_dev.argtypes = [vp, i32, i32, vp, vp, u64, u64, vp, vp, vp, vp]
+        for name in ("redgpu_match_batch_dev", "redgpu_search_batch_dev"):
+            f = getattr(l, name)
+            f.restype = C.c_int
+            f.argtypes = [vp, i32, i32, vp, vp, u64, u64, vp, vp, vp, vp]
         _lib = l
     return _lib
 

@@ -7,7 +7,7 @@
 
 namespace redgpu {
 
-enum Verb : int { kCheck = 0, kMatch = 1, kScan = 2 };
+enum Verb : int { kCheck = 0, kMatch = 1, kScan = 2, kSearch = 3 };
 
 // Device-resident DFA image (pointers are device addresses). Built once per redgpu_dfa.
 struct DevDfa {

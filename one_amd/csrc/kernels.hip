@@ -265,6 +265,51 @@ __device__ int32_t scanLane(const T &tab, const LaneCtx &c, const uint8_t *p, ui
   return result;
 }
 
+// include/Matcher.h:557-640 searchCore: sliding-window match; the leader is only PEEKED
+// (lookingAt), so no start position is skipped - unlike scanCore
+template <class T>
+__device__ int32_t searchLane(const T &tab, const LaneCtx &c, const uint8_t *p, uint64_t n,
+                              int style, bool lead, uint64_t &startOut, uint64_t &endOut) {
+  startOut = 0;
+  endOut = 0;
+  int32_t result = c.resultOf(c.init);
+  uint64_t matchStart = 0, matchEnd = 0;
+  for (uint64_t idx = 0; idx < n; ++idx) {
+    if (lead && !lookingAt(c, p, idx, n)) continue;
+    uint32_t s = c.init;
+    int32_t prev = 0;
+    matchStart = idx;
+    matchEnd = idx;
+    for (uint64_t q = idx; q < n; ++q) {
+      const uint32_t was = s;
+      s = tab.next(s, p[q]);
+      if (was == c.init && s != was) matchStart = q;
+      if (s >= c.firstAccept) {
+        result = c.res[s];
+        if (style == kStyFirst) {
+          if (prev && result != prev) { result = prev; break; }
+          prev = result;
+        }
+        matchEnd = q + 1;
+        if (style == kStyInstant) break;
+        if (style == kStyTangent || style == kStyLast) prev = result;
+      } else {
+        result = 0;
+        if (style == kStyFirst && prev > 0) { result = prev; break; }
+        if (style == kStyTangent && prev > 0) break;
+        if (s < c.nPureDead) break;
+      }
+    }
+    if ((style == kStyTangent || style == kStyLast) && result == 0 && prev > 0) result = prev;
+    if (result > 0) break;
+  }
+  if (result != 0) {
+    startOut = matchStart;
+    endOut = matchEnd;
+  }
+  return result;
+}
+
 // dynamic LDS: [equiv 256][leader 256][table (LDS kinds only)].  An LDS-resident table is
 // shared by one 1024-thread workgroup per CU; a table in HBM/L2 runs 256-thread workgroups.
 template <int KIND, int kGenericThreads>
@@ -306,7 +351,8 @@ k_generic(DevDfa d, Batch b, int verb, int style, int lead) {
       b.result[line] = scanLane(tab, c, p, n, style, lead != 0);
     } else {
       uint64_t st, en;
-      b.result[line] = matchLane(tab, c, p, n, style, lead != 0, st, en);
+      b.result[line] = verb == kSearch ? searchLane(tab, c, p, n, style, lead != 0, st, en)
+                                       : matchLane(tab, c, p, n, style, lead != 0, st, en);
       if (b.start) b.start[line] = st;
       if (b.end) b.end[line] = en;
     }

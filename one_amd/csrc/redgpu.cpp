@@ -309,6 +309,19 @@ int redgpu_scan_batch(const redgpu_dfa *dfa, int style, int do_leader, const uin
                  nullptr);
 }
 
+int redgpu_search_batch(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                        const uint64_t *offsets, uint64_t stride, uint64_t n, int32_t *result,
+                        uint64_t *start, uint64_t *end) {
+  return runHost(dfa, kSearch, style, do_leader, data, offsets, stride, n, result, start, end);
+}
+
+int redgpu_search_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                            const uint64_t *offsets, uint64_t stride, uint64_t n,
+                            int32_t *result, uint64_t *start, uint64_t *end, void *stream) {
+  return runDev(dfa, kSearch, style, do_leader, data, offsets, stride, n, result, start, end,
+                static_cast<hipStream_t>(stream));
+}
+
 int redgpu_check_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
                            const uint64_t *offsets, uint64_t stride, uint64_t n,
                            int32_t *result, void *stream) {

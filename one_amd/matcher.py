@@ -156,11 +156,11 @@ def _run(verb: str, exe: Executable, style, do_leader, data, offsets, stride, n,
             res, st, en = out
         stream = torch.cuda.current_stream(dev).cuda_stream
         op = offsets.data_ptr() if offsets is not None else None
-        if verb == "match":
-            rc = l.redgpu_match_batch_dev(exe._h, style, lead, data.data_ptr(), op, stride, n,
-                                          res.data_ptr(),
-                                          st.data_ptr() if st is not None else None,
-                                          en.data_ptr() if en is not None else None, stream)
+        if verb in ("match", "search"):
+            fdev = l.redgpu_match_batch_dev if verb == "match" else l.redgpu_search_batch_dev
+            rc = fdev(exe._h, style, lead, data.data_ptr(), op, stride, n,
+                      res.data_ptr(), st.data_ptr() if st is not None else None,
+                      en.data_ptr() if en is not None else None, stream)
         else:
             f = l.redgpu_check_batch_dev if verb == "check" else l.redgpu_scan_batch_dev
             rc = f(exe._h, style, lead, data.data_ptr(), op, stride, n, res.data_ptr(), stream)
@@ -184,10 +184,11 @@ def _run(verb: str, exe: Executable, style, do_leader, data, offsets, stride, n,
     en = np.zeros(n, dtype=np.uint64) if want_end else None
     op = offsets.ctypes.data if offsets is not None else None
     dp = a.ctypes.data if a.size else None
-    if verb == "match":
-        rc = l.redgpu_match_batch(exe._h, style, lead, dp, op, stride, n, res.ctypes.data,
-                                  st.ctypes.data if st is not None else None,
-                                  en.ctypes.data if en is not None else None)
+    if verb in ("match", "search"):
+        fhost = l.redgpu_match_batch if verb == "match" else l.redgpu_search_batch
+        rc = fhost(exe._h, style, lead, dp, op, stride, n, res.ctypes.data,
+                   st.ctypes.data if st is not None else None,
+                   en.ctypes.data if en is not None else None)
     else:
         f = l.redgpu_check_batch if verb == "check" else l.redgpu_scan_batch
         rc = f(exe._h, style, lead, dp, op, stride, n, res.ctypes.data)
@@ -215,6 +216,14 @@ def match_batch(exe, data, style, do_leader=True, *, offsets=None, stride=0, n=N
                 out)
 
 
+def search_batch(exe, data, style, do_leader=True, *, offsets=None, stride=0, n=None,
+                 want_start=True, want_end=True, out=None):
+    """search<style,doLeader> over every line (include/Matcher.h:557-640): the first match found
+    sliding over the line -> (result, start, end) like match_batch."""
+    return _run("search", exe, style, do_leader, data, offsets, stride, n, want_start, want_end,
+                out)
+
+
 # single-input forms keep the reference's signatures; they are batches of one ON THE GPU
 def check(exe, text: bytes, style, do_leader=True) -> int:
     return int(check_batch(exe, text, style, do_leader, offsets=[0, len(text)])[0])
@@ -226,4 +235,9 @@ def scan(exe, text: bytes, style, do_leader=True) -> int:
 
 def match(exe, text: bytes, style, do_leader=True):
     r, s, e = match_batch(exe, text, style, do_leader, offsets=[0, len(text)])
+    return int(r[0]), int(s[0]), int(e[0])
+
+
+def search(exe, text: bytes, style, do_leader=True):
+    r, s, e = search_batch(exe, text, style, do_leader, offsets=[0, len(text)])
     return int(r[0]), int(s[0]), int(e[0])

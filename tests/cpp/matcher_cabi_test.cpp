@@ -37,6 +37,10 @@ int main(int argc, char **argv) {
     EXPECT_EQ(0, oc.result_);
     EXPECT_EQ(size_t(0), oc.end_);
     EXPECT_EQ(1, scan(rex, ".,_123", styInstant));  // :417-460
+    Outcome so = search(rex, ".,_123abcde", styLast);  // :555-598 searchLast
+    EXPECT_EQ(3, so.result_);
+    EXPECT_EQ(size_t(3), so.start_);
+    EXPECT_EQ(size_t(10), so.end_);
     EXPECT_EQ(2, (match<styTangent, true>(rex, "123abcd").result_));  // :266-313
   }
   // test/matcher.cpp:149-163 matchLast

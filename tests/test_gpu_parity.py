@@ -20,6 +20,8 @@ def _gpu_call(exe, verb, style, lead, text):
         return one_amd.check(exe, text, STY[style], lead)
     if verb == "scan":
         return one_amd.scan(exe, text, STY[style], lead)
+    if verb == "search":
+        return one_amd.search(exe, text, STY[style], lead)
     return one_amd.match(exe, text, STY[style], lead)
 
 
@@ -36,8 +38,6 @@ def test_kat_matcher_cpp_on_gpu():
     for name, fmt, blob, calls in kat_items():
         exe = one_amd.Executable(blob)
         for c in calls:
-            if c["verb"] == "search":
-                continue  # searchCore is a "next" row
             got = _gpu_call(exe, c["verb"], c["style"], c["lead"], unb64(c["text"]))
             exp = c["expect"]
             if isinstance(exp, int):
@@ -46,7 +46,7 @@ def test_kat_matcher_cpp_on_gpu():
                 for g, e in zip(got, exp):
                     assert e is None or g == e, (name, fmt, c, got)
             n += 1
-    assert n > 250
+    assert n > 400
 
 
 def test_omnibus_table_on_gpu():
@@ -74,12 +74,13 @@ def test_reference_vectors_on_gpu(name, mode):
     exe = one_amd.Executable(load_dfa(name), force_generic=(mode == "generic"),
                              force_global=(mode == "global"))
     data, offsets = vec["data"], vec["offsets"]
-    for verb in ("check", "match", "scan"):
+    for verb in ("check", "match", "scan", "search"):
         for si in range(1, 6):
             for lead in (0, 1):
                 er, es, ee = expect_of(vec, verb, si, lead)
-                if verb == "match":
-                    r, s, e = one_amd.match_batch(exe, data, si, lead, offsets=offsets)
+                if verb in ("match", "search"):
+                    fn = one_amd.match_batch if verb == "match" else one_amd.search_batch
+                    r, s, e = fn(exe, data, si, lead, offsets=offsets)
                     assert np.array_equal(s, es) and np.array_equal(e, ee), (name, verb, si, lead)
                 elif verb == "check":
                     r = one_amd.check_batch(exe, data, si, lead, offsets=offsets)

@@ -27,7 +27,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         agg = collections.defaultdict(list)
         for row in csv.DictReader(open(f)):
             if "k_stream" in row["Kernel_Name"]:
-                summary["kernel"] = row["Kernel_Name"].split("(")[0].strip()
+                summary["kernel"] = row["Kernel_Name"].split("(redgpu::DevDfa")[0].strip()
                 agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
         for k, v in agg.items():
             summary["counters"][k] = sum(v) / len(v)

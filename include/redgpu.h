@@ -129,6 +129,15 @@ int redgpu_search_batch(const redgpu_dfa *dfa, int style, int do_leader, const u
                         const uint64_t *offsets, uint64_t stride, uint64_t n, int32_t *result,
                         uint64_t *start, uint64_t *end);
 
+/*   redgpu_collect_batch <-> Red::collect(string_view, vector<Outcome>&)  include/Red.h:115,
+ *                            lib/Red.cpp:103-116: every non-overlapping match of each line, in
+ *                            order (repeated search<styLast,false>).  Line i's records go to
+ *                            result/start/end[i*cap .. i*cap+cap); counts[i] = matches FOUND,
+ *                            which may exceed cap (then only the first cap are stored). */
+int redgpu_collect_batch(const redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,
+                         uint64_t stride, uint64_t n, uint64_t cap, uint64_t *counts,
+                         int32_t *result, uint64_t *start, uint64_t *end);
+
 /* ---- the same verbs over DEVICE-resident buffers, asynchronous on `stream` ---------------
  * data/offsets/result/start/end are device pointers on the handle's device; `stream` is a
  * hipStream_t (NULL = the default stream).  Nothing is allocated, copied or synchronised. */
@@ -144,6 +153,10 @@ int redgpu_scan_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, const
 int redgpu_search_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
                             const uint64_t *offsets, uint64_t stride, uint64_t n,
                             int32_t *result, uint64_t *start, uint64_t *end, void *stream);
+
+int redgpu_collect_batch_dev(const redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,
+                             uint64_t stride, uint64_t n, uint64_t cap, uint64_t *counts,
+                             int32_t *result, uint64_t *start, uint64_t *end, void *stream);
 
 /* Name of the kernel the last *_batch* call on this thread launched (for profiles), or "". */
 const char *redgpu_last_kernel(void);

@@ -8,8 +8,10 @@ extension; the first call does, and fails loudly if it is not built.
 """
 from .matcher import (Executable, Style, RedExcept, RedExceptApi, RedExceptExec,  # noqa: F401
                       RedExceptLimit, RedExceptHip, check, check_batch, check_header, match,
-                      match_batch, scan, scan_batch, search, search_batch, last_kernel, styInstant, styFirst,
+                      match_batch, scan, scan_batch, search, search_batch, collect,
+                      collect_batch, last_kernel, styInstant, styFirst,
                       styTangent, styLast, styFull)
 
 __all__ = ["Executable", "Style", "check", "match", "scan", "check_batch", "match_batch",
-           "scan_batch", "search", "search_batch", "check_header", "last_kernel"]
+           "scan_batch", "search", "search_batch", "collect", "collect_batch", "check_header",
+           "last_kernel"]

@@ -100,6 +100,10 @@ def lib() -> C.CDLL:
             f = getattr(l, name)
             f.restype = C.c_int
             f.argtypes = [vp, i32, i32, vp, vp, u64, u64, vp, vp, vp, vp]
+        l.redgpu_collect_batch.restype = C.c_int
+        l.redgpu_collect_batch.argtypes = [vp, vp, vp, u64, u64, u64, vp, vp, vp, vp]
+        l.redgpu_collect_batch_dev.restype = C.c_int
+        l.redgpu_collect_batch_dev.argtypes = [vp, vp, vp, u64, u64, u64, vp, vp, vp, vp, vp]
         _lib = l
     return _lib
 

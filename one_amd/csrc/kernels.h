@@ -47,6 +47,11 @@ struct LaunchCfg {
 hipError_t launchBatch(const DevDfa &dfa, const Batch &b, int verb, int style, int doLeader,
                        const LaunchCfg &cfg, hipStream_t stream, const char **kernelName);
 
+// Red::collect per line (lib/Red.cpp:103-116): up to `cap` records per line at
+// [line*cap, line*cap+cap) of result/start/end, counts[line] = number found.
+hipError_t launchCollect(const DevDfa &dfa, const Batch &b, uint64_t cap, uint64_t *counts,
+                         const LaunchCfg &cfg, hipStream_t stream);
+
 // True when the specialised fixed-stride kernels can run this DFA at all.
 bool fastPathEligible(const DevDfa &dfa);
 

@@ -544,6 +544,55 @@ k_leader_filter(DevDfa d, Batch b) {
 
 #include "k_stream.h"
 
+// Red::collect (lib/Red.cpp:103-116): all non-overlapping matches of a line, in order, by
+// repeated search<styLast,false> from the end of the previous match.  One line per lane.
+template <int KIND, int kThreads>
+__global__ void __launch_bounds__(kThreads)
+k_collect(DevDfa d, Batch b, uint64_t cap, uint64_t *counts) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  uint8_t *eq = lds;
+  uint8_t *leader = lds + 256;
+  uint8_t *ldsTab = lds + 512;
+  for (uint32_t i = threadIdx.x; i < 512 / 4; i += kThreads)
+    reinterpret_cast<uint32_t *>(lds)[i] = reinterpret_cast<const uint32_t *>(d.equivLeader)[i];
+  if (Tab<KIND>::kInLds) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(d.table);
+    uint4 *dst = reinterpret_cast<uint4 *>(ldsTab);
+    for (uint32_t i = threadIdx.x; i < d.tableBytes / 16; i += kThreads) dst[i] = src[i];
+  }
+  __syncthreads();
+  const Tab<KIND> tab(Tab<KIND>::kInLds ? ldsTab : d.table, eq, d.nClasses);
+  LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
+            d.leaderLen};
+  const uint64_t step = uint64_t(gridDim.x) * kThreads;
+  for (uint64_t line = uint64_t(blockIdx.x) * kThreads + threadIdx.x; line < b.n; line += step) {
+    const uint8_t *p;
+    uint64_t n;
+    if (b.offsets) {
+      const uint64_t o = b.offsets[line];
+      p = b.data + o;
+      n = b.offsets[line + 1] - o;
+    } else {
+      p = b.data + line * b.stride;
+      n = b.stride;
+    }
+    uint64_t found = 0, pos = 0;
+    while (pos < n) {
+      uint64_t st, en;
+      const int32_t r = searchLane(tab, c, p + pos, n - pos, kStyLast, false, st, en);
+      if (!(r > 0)) break;
+      if (found < cap) {
+        b.result[line * cap + found] = r;
+        if (b.start) b.start[line * cap + found] = pos + st;
+        if (b.end) b.end[line * cap + found] = pos + en;
+      }
+      ++found;
+      pos += en;
+    }
+    counts[line] = found;
+  }
+}
+
 template <class K>
 hipError_t setLds(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return hipSuccess;
@@ -566,6 +615,23 @@ hipError_t launchGeneric(const DevDfa &d, const Batch &b, int verb, int style, i
   if (blocks == 0) blocks = 1;
   hipLaunchKernelGGL((k_generic<KIND, kThreads>), dim3(uint32_t(blocks)), dim3(kThreads),
                      ldsBytes, stream, d, b, verb, style, lead);
+  return hipGetLastError();
+}
+
+template <int KIND>
+hipError_t launchCollectK(const DevDfa &d, const Batch &b, uint64_t cap, uint64_t *counts,
+                          const LaunchCfg &cfg, hipStream_t stream) {
+  constexpr int kThreads = Tab<KIND>::kInLds ? 1024 : 256;
+  const size_t ldsBytes = 512 + (Tab<KIND>::kInLds ? size_t(d.tableBytes) : 0);
+  hipError_t e = setLds(k_collect<KIND, kThreads>, ldsBytes);
+  if (e != hipSuccess) return e;
+  uint64_t blocks = (b.n + kThreads - 1) / kThreads;
+  const uint64_t perCu = Tab<KIND>::kInLds ? (ldsBytes <= 80 * 1024 ? 2 : 1) : 8;
+  const uint64_t capBlocks = uint64_t(cfg.numCUs) * perCu;
+  if (blocks > capBlocks) blocks = capBlocks;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL((k_collect<KIND, kThreads>), dim3(uint32_t(blocks)), dim3(kThreads), ldsBytes,
+                     stream, d, b, cap, counts);
   return hipGetLastError();
 }
 
@@ -618,6 +684,23 @@ hipError_t launchFixedS(int style, const DevDfa &d, const Batch &b, uint32_t sta
 bool fastPathEligible(const DevDfa &d) {
   return d.tableKind == REDGPU_TAB_LDS_FUSED_U8 && d.deadAbsorbing &&
          size_t(d.tableBytes) + size_t(d.nStates) * 4 <= 150 * 1024;
+}
+
+hipError_t launchCollect(const DevDfa &d, const Batch &b, uint64_t cap, uint64_t *counts,
+                         const LaunchCfg &cfg, hipStream_t stream) {
+  if (b.n == 0) return hipSuccess;
+  switch (d.tableKind) {
+  case REDGPU_TAB_LDS_FUSED_U8:
+    return launchCollectK<REDGPU_TAB_LDS_FUSED_U8>(d, b, cap, counts, cfg, stream);
+  case REDGPU_TAB_LDS_FUSED_U16:
+    return launchCollectK<REDGPU_TAB_LDS_FUSED_U16>(d, b, cap, counts, cfg, stream);
+  case REDGPU_TAB_LDS_CLASS_U16:
+    return launchCollectK<REDGPU_TAB_LDS_CLASS_U16>(d, b, cap, counts, cfg, stream);
+  case REDGPU_TAB_GLOBAL_U16:
+    return launchCollectK<REDGPU_TAB_GLOBAL_U16>(d, b, cap, counts, cfg, stream);
+  default:
+    return launchCollectK<REDGPU_TAB_GLOBAL_U32>(d, b, cap, counts, cfg, stream);
+  }
 }
 
 hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int doLeader,

@@ -157,6 +157,25 @@ int runHost(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint
   return REDGPU_OK;
 }
 
+int collectDev(const redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets, uint64_t stride,
+               uint64_t n, uint64_t cap, uint64_t *counts, int32_t *result, uint64_t *start,
+               uint64_t *end, hipStream_t stream) {
+  if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
+  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (n == 0) return REDGPU_OK;
+  if (!counts) return fail(REDGPU_EAPI, "null counts buffer");
+  if (cap && !result) return fail(REDGPU_EAPI, "null result buffer");
+  if (!data && (offsets || stride)) return fail(REDGPU_EAPI, "null data buffer");
+  DeviceScope scope(dfa->device);
+  if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  Batch b{data, offsets, stride, n, result, start, end};
+  LaunchCfg cfg{dfa->numCUs, 0};
+  hipError_t e = launchCollect(dfa->dev, b, cap, counts, cfg, stream);
+  tlsKernel = "k_collect";
+  if (e != hipSuccess) return failHip(e, "kernel launch");
+  return REDGPU_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -320,6 +339,62 @@ int redgpu_search_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, con
                             int32_t *result, uint64_t *start, uint64_t *end, void *stream) {
   return runDev(dfa, kSearch, style, do_leader, data, offsets, stride, n, result, start, end,
                 static_cast<hipStream_t>(stream));
+}
+
+int redgpu_collect_batch_dev(const redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,
+                             uint64_t stride, uint64_t n, uint64_t cap, uint64_t *counts,
+                             int32_t *result, uint64_t *start, uint64_t *end, void *stream) {
+  return collectDev(dfa, data, offsets, stride, n, cap, counts, result, start, end,
+                    static_cast<hipStream_t>(stream));
+}
+
+int redgpu_collect_batch(const redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,
+                         uint64_t stride, uint64_t n, uint64_t cap, uint64_t *counts,
+                         int32_t *result, uint64_t *start, uint64_t *end) {
+  if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
+  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (n == 0) return REDGPU_OK;
+  if (!counts) return fail(REDGPU_EAPI, "null counts buffer");
+  const uint64_t total = offsets ? offsets[n] : stride * n;
+  if (total && !data) return fail(REDGPU_EAPI, "null data buffer");
+  DeviceScope scope(dfa->device);
+  if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  uint8_t *dData = nullptr;
+  uint64_t *dOff = nullptr, *dCnt = nullptr, *dStart = nullptr, *dEnd = nullptr;
+  int32_t *dRes = nullptr;
+  auto cleanup = [&]() {
+    for (void *q : {(void *)dData, (void *)dOff, (void *)dCnt, (void *)dRes, (void *)dStart, (void *)dEnd})
+      if (q) (void)hipFree(q);
+  };
+  int rc = REDGPU_OK;
+#define CH_TRY(expr, what)                                                    \
+  do {                                                                        \
+    hipError_t e_ = (expr);                                                   \
+    if (e_ != hipSuccess) { rc = failHip(e_, what); cleanup(); return rc; }   \
+  } while (0)
+  const uint64_t slots = n * cap;
+  CH_TRY(hipMalloc(reinterpret_cast<void **>(&dData), total + 16), "hipMalloc data");
+  CH_TRY(hipMalloc(reinterpret_cast<void **>(&dCnt), n * 8), "hipMalloc counts");
+  CH_TRY(hipMalloc(reinterpret_cast<void **>(&dRes), (slots + 1) * 4), "hipMalloc result");
+  if (start) CH_TRY(hipMalloc(reinterpret_cast<void **>(&dStart), (slots + 1) * 8), "hipMalloc start");
+  if (end) CH_TRY(hipMalloc(reinterpret_cast<void **>(&dEnd), (slots + 1) * 8), "hipMalloc end");
+  if (offsets) {
+    CH_TRY(hipMalloc(reinterpret_cast<void **>(&dOff), (n + 1) * 8), "hipMalloc offsets");
+    CH_TRY(hipMemcpy(dOff, offsets, (n + 1) * 8, hipMemcpyHostToDevice), "copy offsets");
+  }
+  if (total) CH_TRY(hipMemcpy(dData, data, total, hipMemcpyHostToDevice), "copy data");
+  rc = collectDev(dfa, dData, dOff, stride, n, cap, dCnt, dRes, dStart, dEnd, nullptr);
+  if (rc != REDGPU_OK) { cleanup(); return rc; }
+  CH_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  CH_TRY(hipMemcpy(counts, dCnt, n * 8, hipMemcpyDeviceToHost), "copy counts");
+  if (slots) {
+    CH_TRY(hipMemcpy(result, dRes, slots * 4, hipMemcpyDeviceToHost), "copy result");
+    if (start) CH_TRY(hipMemcpy(start, dStart, slots * 8, hipMemcpyDeviceToHost), "copy start");
+    if (end) CH_TRY(hipMemcpy(end, dEnd, slots * 8, hipMemcpyDeviceToHost), "copy end");
+  }
+#undef CH_TRY
+  cleanup();
+  return REDGPU_OK;
 }
 
 int redgpu_check_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,

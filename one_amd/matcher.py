@@ -224,6 +224,35 @@ def search_batch(exe, data, style, do_leader=True, *, offsets=None, stride=0, n=
                 out)
 
 
+def collect_batch(exe, data, cap, *, offsets=None, stride=0, n=None):
+    """Red::collect (lib/Red.cpp:103-116) over every line: all non-overlapping matches in order.
+    Host arrays in, host arrays out: (counts uint64[n], result int32[n,cap], start uint64[n,cap],
+    end uint64[n,cap]); counts[i] may exceed cap (only the first cap records are kept)."""
+    a = _host_u8(data)
+    if offsets is not None:
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        stride = 0
+    elif n is None:
+        n = a.size // stride if stride else 0
+    counts = np.zeros(n, dtype=np.uint64)
+    res = np.zeros((n, cap), dtype=np.int32)
+    st = np.zeros((n, cap), dtype=np.uint64)
+    en = np.zeros((n, cap), dtype=np.uint64)
+    _check(_lib.lib().redgpu_collect_batch(
+        exe._h, a.ctypes.data if a.size else None,
+        offsets.ctypes.data if offsets is not None else None, stride, n, cap, counts.ctypes.data,
+        res.ctypes.data, st.ctypes.data, en.ctypes.data))
+    return counts, res, st, en
+
+
+def collect(exe, text: bytes, cap: int = 64):
+    """Red::collect on one text -> list of (result, start, end)."""
+    counts, res, st, en = collect_batch(exe, text, cap, offsets=[0, len(text)])
+    k = int(min(counts[0], cap))
+    return [(int(res[0, i]), int(st[0, i]), int(en[0, i])) for i in range(k)]
+
+
 # single-input forms keep the reference's signatures; they are batches of one ON THE GPU
 def check(exe, text: bytes, style, do_leader=True) -> int:
     return int(check_batch(exe, text, style, do_leader, offsets=[0, len(text)])[0])

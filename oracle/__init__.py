@@ -79,6 +79,13 @@ def _orc():
             f.restype = C.c_int32
             f.argtypes = [C.POINTER(_Dfa), C.c_void_p, C.c_size_t, C.c_int, C.c_int,
                           _u64p, _u64p]
+        lib.oracle_collect.restype = C.c_uint64
+        lib.oracle_collect.argtypes = [C.POINTER(_Dfa), C.c_void_p, C.c_size_t, C.c_uint64,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.oracle_collect_batch.restype = None
+        lib.oracle_collect_batch.argtypes = [C.POINTER(_Dfa), C.c_void_p, C.c_void_p, C.c_uint64,
+                                             C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]
         lib.oracle_batch.restype = None
         lib.oracle_batch.argtypes = [C.POINTER(_Dfa), C.c_int, C.c_int, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
@@ -187,6 +194,35 @@ class CpuOracle(_Batchable):
         _orc().oracle_batch(C.byref(self._d), verb, style, lead, data, offsets, stride,
                             line_len, n, res, st, en, threads)
 
+    def collect(self, text: bytes, cap: int = 64):
+        """Red::collect: list of (result, start, end), and the number found."""
+        res = np.zeros(cap, dtype=np.int32)
+        st = np.zeros(cap, dtype=np.uint64)
+        en = np.zeros(cap, dtype=np.uint64)
+        k = _orc().oracle_collect(C.byref(self._d), text, len(text), cap, res.ctypes.data,
+                                  st.ctypes.data, en.ctypes.data)
+        m = min(k, cap)
+        return [(int(res[i]), int(st[i]), int(en[i])) for i in range(m)], int(k)
+
+    def collect_batch(self, data, cap, *, offsets=None, stride=0, n=None):
+        """-> counts uint64[n], result int32[n,cap], start uint64[n,cap], end uint64[n,cap]"""
+        data = _as_u8(data)
+        if offsets is not None:
+            offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+            n = len(offsets) - 1
+        elif n is None:
+            n = len(data) // stride if stride else 0
+        counts = np.zeros(n, dtype=np.uint64)
+        res = np.zeros((n, cap), dtype=np.int32)
+        st = np.zeros((n, cap), dtype=np.uint64)
+        en = np.zeros((n, cap), dtype=np.uint64)
+        if n:
+            _orc().oracle_collect_batch(C.byref(self._d), data.ctypes.data,
+                                        offsets.ctypes.data if offsets is not None else None,
+                                        int(stride), int(stride), n, cap, counts.ctypes.data,
+                                        res.ctypes.data, st.ctypes.data, en.ctypes.data)
+        return counts, res, st, en
+
 
 # ------------------------------------------------------------------------------------------
 _libref = None
@@ -222,6 +258,9 @@ def _ref():
             f.restype = None
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, _i32p, _u64p,
                           _u64p]
+        lib.ref_collect.restype = C.c_uint64
+        lib.ref_collect.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint64,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]
         lib.ref_batch.restype = None
         lib.ref_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p,
@@ -277,6 +316,17 @@ def ref_syn_dfa(nstates, seed, accept_every=7, max_result=5, fmt=FMT_AUTO) -> by
     blob = C.string_at(out.value, outlen.value)
     lib.ref_free(out)
     return blob
+
+
+def ref_collect(blob: bytes, text: bytes, cap: int = 64):
+    """The reference's Red::collect (lib/Red.cpp:103-116) -> ([(result,start,end)...], found)."""
+    res = np.zeros(cap, dtype=np.int32)
+    st = np.zeros(cap, dtype=np.uint64)
+    en = np.zeros(cap, dtype=np.uint64)
+    k = _ref().ref_collect(blob, len(blob), text, len(text), cap, res.ctypes.data, st.ctypes.data,
+                           en.ctypes.data)
+    m = min(k, cap)
+    return [(int(res[i]), int(st[i]), int(en[i])) for i in range(m)], int(k)
 
 
 def ref_check_header(blob: bytes):

@@ -386,11 +386,57 @@ def gen_vectors():
         np.savez_compressed(os.path.join(GOLD, "vectors_%s.npz" % name), **arrays)
 
 
+def gen_collect():
+    """Red::collect: the known answer of test/red.cpp:190-221 + reference outputs on the mixed
+    input set for two multi-pattern DFAs."""
+    pats = [("new york", 1, 0), ("new", 2, 0), ("york", 3, 0), ("[0-9]+", 4, 0)]
+    blob = O.ref_compile(pats)
+    text = b"in new york12345, a new 6789 york city"
+    expect = [(1, 3, 11), (4, 11, 16), (2, 20, 23), (4, 24, 28), (3, 29, 33)]
+    got, k = O.ref_collect(blob, text)
+    assert got == expect and k == 5, got
+    assert O.ref_collect(blob, b"new york")[1] == 1
+    out = dict(kat=dict(src="test/red.cpp:190-221", reda=b64(blob), text=b64(text),
+                        expect=[list(x) for x in expect]), sets={})
+    rng = np.random.default_rng(0xC011EC7)
+    ins = inputs_for("collect", rng)[:1200]
+    ins += [text, b"new york", b"", b"newnewnew", b"12 34 56 new york york new 7"]
+    cap = 16
+    arrays = {}
+    for name, b in (("newyork4", blob), ("num3", O.ref_compile(NUM3)),
+                    ("newyork_loose", O.ref_compile([("New", 1, LS), ("New York", 2, LS),
+                                                     ("York", 3, LS)]))):
+        cpu = O.CpuOracle(b)
+        counts = np.zeros(len(ins), dtype=np.uint64)
+        res = np.zeros((len(ins), cap), dtype=np.int32)
+        st = np.zeros((len(ins), cap), dtype=np.uint64)
+        en = np.zeros((len(ins), cap), dtype=np.uint64)
+        for i, t in enumerate(ins):
+            got, k = O.ref_collect(b, t, cap)
+            assert (got, k) == cpu.collect(t, cap), (name, t)
+            counts[i] = k
+            for j, (r, s_, e_) in enumerate(got):
+                res[i, j], st[i, j], en[i, j] = r, s_, e_
+        arrays[name + "_blob"] = np.frombuffer(b, dtype=np.uint8)
+        arrays[name + "_counts"], arrays[name + "_res"] = counts, res
+        arrays[name + "_start"], arrays[name + "_end"] = st, en
+    data = np.frombuffer(b"".join(ins), dtype=np.uint8)
+    offsets = np.zeros(len(ins) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(x) for x in ins])
+    arrays["data"], arrays["offsets"] = data, offsets
+    arrays["cap"] = np.array([cap])
+    np.savez_compressed(os.path.join(GOLD, "collect_vectors.npz"), **arrays)
+    with open(os.path.join(GOLD, "collect_kat.json"), "w") as f:
+        json.dump(out["kat"], f)
+    print("collect: kat + %d inputs x 3 dfas" % len(ins))
+
+
 def main():
     os.makedirs(os.path.join(GOLD, "dfas"), exist_ok=True)
     gen_kat()
     gen_omnibus()
     gen_vectors()
+    gen_collect()
 
 
 if __name__ == "__main__":

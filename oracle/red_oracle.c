@@ -426,6 +426,37 @@ int32_t oracle_search(const oracle_dfa *d, const uint8_t *p, size_t n, int style
 #undef CALL
 }
 
+/* ---- lib/Red.cpp:103-116 Red::collect ------------------------------------------------- */
+uint64_t oracle_collect(const oracle_dfa *d, const uint8_t *p, size_t n, uint64_t cap,
+                        int32_t *res, uint64_t *start, uint64_t *end) {
+  uint64_t found = 0;
+  size_t pos = 0;
+  while (pos < n) {
+    uint64_t s = 0, e = 0;
+    int32_t r = oracle_search(d, p + pos, n - pos, ORA_STY_LAST, 0, &s, &e);
+    if (!(r > 0))
+      break;
+    if (found < cap) {
+      res[found] = r;
+      start[found] = pos + s;
+      end[found] = pos + e;
+    }
+    ++found;
+    pos += e;
+  }
+  return found;
+}
+
+void oracle_collect_batch(const oracle_dfa *d, const uint8_t *data, const uint64_t *offsets,
+                          uint64_t stride, uint64_t lineLen, uint64_t n, uint64_t cap,
+                          uint64_t *counts, int32_t *res, uint64_t *start, uint64_t *end) {
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint8_t *p = offsets ? data + offsets[i] : data + i * stride;
+    size_t len = offsets ? (size_t)(offsets[i + 1] - offsets[i]) : (size_t)lineLen;
+    counts[i] = oracle_collect(d, p, len, cap, res + i * cap, start + i * cap, end + i * cap);
+  }
+}
+
 /* ---- batch: the callers' outer loop, N threads over contiguous shards
  * (tools/thr_red.cpp:36-47,86-91; tools/bench.cpp:60-71) -------------------------------- */
 typedef struct {

@@ -67,6 +67,17 @@ int32_t oracle_match(const oracle_dfa *d, const uint8_t *p, size_t n, int style,
 int32_t oracle_search(const oracle_dfa *d, const uint8_t *p, size_t n, int style, int doLeader,
                       uint64_t *start, uint64_t *end);
 
+/* lib/Red.cpp:103-116 Red::collect(string_view): all non-overlapping matches in order, by
+ * repeated search<styLast,false> from the end of the previous match.  Writes at most `cap`
+ * records; returns the number FOUND (may exceed cap). */
+uint64_t oracle_collect(const oracle_dfa *d, const uint8_t *p, size_t n, uint64_t cap,
+                        int32_t *res, uint64_t *start, uint64_t *end);
+
+/* batch form of oracle_collect: per line i, records go to [i*cap, i*cap+cap), counts[i] = found */
+void oracle_collect_batch(const oracle_dfa *d, const uint8_t *data, const uint64_t *offsets,
+                          uint64_t stride, uint64_t lineLen, uint64_t n, uint64_t cap,
+                          uint64_t *counts, int32_t *res, uint64_t *start, uint64_t *end);
+
 /* The callers' per-input loop (tools/bench.cpp:60-71, tools/thr_red.cpp:36-47,86-91):
  * line i = data[offsets[i], offsets[i+1]) or, with offsets == NULL,
  * data[i*stride, i*stride + lineLen).  start/end may be NULL.  nthreads contiguous shards. */

@@ -11,6 +11,7 @@
  *   - Executable(gCopyTag, sv)                   (include/Executable.h:37)
  *   - check/match/scan/search<style,doLeader>    (include/Matcher.h:133-182)
  *   - checkHeader                                (include/Serializer.h:109)
+ *   - Red(gCopyTag, sv), Red::collect            (include/Red.h:103,115; lib/Red.cpp:103-116)
  * so that (1) the C restatement in oracle/red_oracle.c can be validated against the real
  * thing, (2) golden vectors can be generated (oracle/gen_golden.py) and (3) bench.py's
  * cpu_baseline leg can time the reference itself ("kind": "reference").
@@ -31,6 +32,7 @@
 #include "Matcher.h"
 #include "Minimizer.h"
 #include "Parser.h"
+#include "Red.h"
 #include "Serializer.h"
 
 using namespace zezax::red;
@@ -224,6 +226,20 @@ void ref_search(void *ex, const void *p, size_t n, int style, int lead, int32_t 
   *res = oc.result_;
   *start = oc.start_;
   *end = oc.end_;
+}
+
+/* Red::collect over one text; writes at most cap records, returns the number found */
+uint64_t ref_collect(const void *blob, size_t len, const void *text, size_t n, uint64_t cap,
+                     int32_t *res, uint64_t *start, uint64_t *end) {
+  Red re(gCopyTag, std::string_view(static_cast<const char *>(blob), len));
+  std::vector<Outcome> out;
+  re.collect(std::string_view(static_cast<const char *>(text), n), out);
+  for (size_t i = 0; i < out.size() && i < cap; ++i) {
+    res[i] = out[i].result_;
+    start[i] = out[i].start_;
+    end[i] = out[i].end_;
+  }
+  return out.size();
 }
 
 /* Batch forms: the outer per-input loop of tools/bench.cpp:60-71 / thr_red.cpp:36-47,

@@ -304,3 +304,34 @@ def test_config5_shape_4k_state_dfa_long_inputs_vs_oracle():
     r, s, e = one_amd.match_batch(exe, data, 4, 0, stride=stride, n=n)
     er, es, ee = cpu.batch("match", 4, 0, data, stride=stride, n=n, threads=8)
     assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee)
+
+
+def test_collect_on_gpu():
+    """Red::collect batch form vs the reference's known answer (test/red.cpp:190-221) and the
+    reference outputs in tests/golden/collect_vectors.npz, for 3 table placements."""
+    import json
+    import os
+    from golden_util import GOLD
+    kat = json.load(open(os.path.join(GOLD, "collect_kat.json")))
+    exe = one_amd.Executable(unb64(kat["reda"]))
+    assert one_amd.collect(exe, unb64(kat["text"])) == [tuple(x) for x in kat["expect"]]
+    assert one_amd.collect(exe, b"new york") == [(1, 0, 8)]
+    assert one_amd.collect(exe, b"") == []
+    vec = np.load(os.path.join(GOLD, "collect_vectors.npz"))
+    cap = int(vec["cap"][0])
+    for name in ("newyork4", "num3", "newyork_loose"):
+        for kw in ({}, {"force_global": True}):
+            exe = one_amd.Executable(vec[name + "_blob"].tobytes(), **kw)
+            counts, res, st, en = one_amd.collect_batch(exe, vec["data"], cap, offsets=vec["offsets"])
+            assert np.array_equal(counts, vec[name + "_counts"]), name
+            # slots beyond min(count, cap) are unspecified: compare the filled prefix only
+            k = np.minimum(counts, cap).astype(np.int64)
+            mask = np.arange(cap)[None, :] < k[:, None]
+            assert np.array_equal(res[mask], vec[name + "_res"][mask])
+            assert np.array_equal(st[mask], vec[name + "_start"][mask])
+            assert np.array_equal(en[mask], vec[name + "_end"][mask])
+    # truncation: cap smaller than the number of matches keeps the first cap records
+    exe = one_amd.Executable(unb64(kat["reda"]))
+    counts, res, st, en = one_amd.collect_batch(exe, unb64(kat["text"]), 2,
+                                                offsets=[0, len(unb64(kat["text"]))])
+    assert int(counts[0]) == 5 and res[0].tolist() == [1, 4] and en[0].tolist() == [11, 16]

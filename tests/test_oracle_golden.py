@@ -86,3 +86,23 @@ def test_reference_vectors(name):
                 assert np.array_equal(r, er), (name, verb, sty, lead)
                 if es is not None:
                     assert np.array_equal(s, es) and np.array_equal(e, ee), (name, verb, sty)
+
+
+def test_collect_kat_and_vectors():
+    """Red::collect (lib/Red.cpp:103-116): the known answer of test/red.cpp:190-221 and the
+    reference's outputs on the mixed input set."""
+    import json
+    import os
+    from golden_util import GOLD
+    kat = json.load(open(os.path.join(GOLD, "collect_kat.json")))
+    cpu = O.CpuOracle(unb64(kat["reda"]))
+    got, k = cpu.collect(unb64(kat["text"]))
+    assert got == [tuple(x) for x in kat["expect"]] and k == 5
+    vec = np.load(os.path.join(GOLD, "collect_vectors.npz"))
+    cap = int(vec["cap"][0])
+    for name in ("newyork4", "num3", "newyork_loose"):
+        cpu = O.CpuOracle(vec[name + "_blob"].tobytes())
+        counts, res, st, en = cpu.collect_batch(vec["data"], cap, offsets=vec["offsets"])
+        assert np.array_equal(counts, vec[name + "_counts"])
+        assert np.array_equal(res, vec[name + "_res"])
+        assert np.array_equal(st, vec[name + "_start"]) and np.array_equal(en, vec[name + "_end"])

@@ -1,0 +1,298 @@
+// k_ragged.h - the streaming kernel for RAGGED lines (offsets[n+1]); included by kernels.hip
+// inside its namespace, after k_stream.h (shares StreamMode / StreamBook).
+//
+// Same machinery as k_stream - fused u8 table at LDS offset 0, 2 lines per lane, whole 64-byte
+// blocks per lane in ping-pong register sets, inline-asm byte step - plus what variable line
+// lengths need:
+//  * a lane's line may end anywhere: `rem` = bytes of the line left at the start of the block
+//    (0..64).  Step IDX is VALID iff IDX < rem; an invalid step still issues its lookup
+//    (uniform instruction stream) but the state is not advanced (one v_cndmask after the
+//    wait), so a finished lane simply holds its final state.  A held state cannot fake a
+//    "left the initial state" event (is-initial == was-initial) and re-recording it as the
+//    last accepting state is harmless; only the END position needs the mask of the previous
+//    step's validity.  8 VALU + 2 SALU per byte per line.
+//  * a wave walks as many blocks as its longest line needs (wave-uniform trip count from a
+//    cross-lane max); finished lanes re-read their last block (L1/L2 hits).
+//  * lines start at arbitrary byte offsets: 16-byte loads at unaligned addresses (the memory
+//    pipeline splits them).  Block reads run up to 63 bytes past a line's end, so lines that
+//    end within the last 64 bytes of the input buffer are NOT walked here (they would read
+//    past the buffer): they are left to a second, tiny launch of k_generic restricted to
+//    exactly those lines (Batch::tailOnly).  Requests stay unconditional and branch-free, so
+//    the compiler's in-order vmcnt counts stay exact.
+//  * an empty line reports the initial state's result (Matcher.h:379,437 with no iterations).
+#pragma once
+
+#define RG_PERM(c) "v_perm_b32 %[a" #c "], %[s" #c "], %[w" #c "], %[sel]\n\t"
+#define RG_READ(c) "ds_read_u8 %[t" #c "], %[a" #c "]\n\t"
+#define RG_VALID(c) "v_cmp_gt_u32_e64 %[v" #c "], %[rem" #c "], %[idx]\n\t"
+#define RG_CMPA(c) "v_cmp_le_u32_e64 %[m" #c "], %[T], %[s" #c "]\n\t"
+#define RG_CMPI(c) "v_cmp_eq_u32_e64 %[i" #c "], %[init], %[s" #c "]\n\t"
+#define RG_ACC(c) "v_cndmask_b32_e64 %[acc" #c "], %[acc" #c "], %[s" #c "], %[m" #c "]\n\t"
+#define RG_MEND(c) "s_and_b64 %[mr" #c "], %[m" #c "], %[rp" #c "]\n\t"
+#define RG_END(c) "v_cndmask_b32_e64 %[e" #c "], %[e" #c "], %[idx], %[mr" #c "]\n\t"
+#define RG_LEAVE(c) "s_andn2_b64 %[l" #c "], %[was" #c "], %[i" #c "]\n\t"
+#define RG_START(c) "v_cndmask_b32_e64 %[st" #c "], %[st" #c "], %[idx], %[l" #c "]\n\t"
+#define RG_WAIT "s_waitcnt lgkmcnt(0)\n\t"
+#define RG_HOLD(c) "v_cndmask_b32_e64 %[t" #c "], %[s" #c "], %[t" #c "], %[v" #c "]\n\t"
+
+#define RG_O_CHAIN(c) [a##c] "=&v"(a[c]), [t##c] "=&v"(t[c]), [v##c] "=&s"(validNow[c])
+#define RG_O_ACC(c) [m##c] "=&s"(m[c]), [mr##c] "=&s"(mr[c]), [acc##c] "+v"(b[c].acc), [e##c] "+v"(b[c].end)
+#define RG_O_START(c) [i##c] "=&s"(isI[c]), [l##c] "=&s"(l[c]), [st##c] "+v"(b[c].start)
+#define RG_I_CHAIN(c) [s##c] "v"(s[c]), [w##c] "v"(w[c]), [rem##c] "v"(rem[c])
+#define RG_I_ACC(c) [rp##c] "s"(validPrev[c])
+#define RG_I_START(c) [was##c] "s"(wasI[c])
+
+// validPrev: lane mask "the state being book-kept was reached by a real transition" (= the
+// previous step was valid); validNow: written here for the next step.
+template <int MODE, int IDX>
+__device__ __forceinline__ void raggedStep(uint32_t (&s)[2], const uint32_t (&w)[2],
+                                           const uint32_t (&rem)[2], StreamBook (&b)[2],
+                                           const uint64_t (&wasI)[2], uint64_t (&isI)[2],
+                                           const uint64_t (&validPrev)[2], uint64_t (&validNow)[2],
+                                           uint32_t sel, uint32_t T, uint32_t init) {
+  uint32_t a[2], t[2];
+  uint64_t m[2], mr[2], l[2];
+  if constexpr (MODE == kSmLastStartEnd) {
+    asm volatile(RG_PERM(0) RG_PERM(1) RG_READ(0) RG_READ(1) RG_VALID(0) RG_VALID(1)
+                 RG_CMPA(0) RG_CMPA(1) RG_CMPI(0) RG_CMPI(1) RG_ACC(0) RG_ACC(1)
+                 RG_MEND(0) RG_MEND(1) RG_END(0) RG_END(1)
+                 RG_LEAVE(0) RG_LEAVE(1) RG_START(0) RG_START(1) RG_WAIT RG_HOLD(0) RG_HOLD(1)
+                 : RG_O_CHAIN(0), RG_O_CHAIN(1), RG_O_ACC(0), RG_O_ACC(1), RG_O_START(0),
+                   RG_O_START(1)
+                 : RG_I_CHAIN(0), RG_I_CHAIN(1), RG_I_ACC(0), RG_I_ACC(1), RG_I_START(0),
+                   RG_I_START(1), [sel] "s"(sel), [T] "s"(T), [init] "s"(init), [idx] "n"(IDX)
+                 : "memory", "scc");
+  } else if constexpr (MODE == kSmLastEnd) {
+    asm volatile(RG_PERM(0) RG_PERM(1) RG_READ(0) RG_READ(1) RG_VALID(0) RG_VALID(1)
+                 RG_CMPA(0) RG_CMPA(1) "s_nop 0\n\t" RG_ACC(0) RG_ACC(1)
+                 RG_MEND(0) RG_MEND(1) RG_END(0) RG_END(1) RG_WAIT RG_HOLD(0) RG_HOLD(1)
+                 : RG_O_CHAIN(0), RG_O_CHAIN(1), RG_O_ACC(0), RG_O_ACC(1)
+                 : RG_I_CHAIN(0), RG_I_CHAIN(1), RG_I_ACC(0), RG_I_ACC(1), [sel] "s"(sel),
+                   [T] "s"(T), [idx] "n"(IDX)
+                 : "memory", "scc");
+  } else if constexpr (MODE == kSmFullStart) {
+    asm volatile(RG_PERM(0) RG_PERM(1) RG_READ(0) RG_READ(1) RG_VALID(0) RG_VALID(1)
+                 RG_CMPI(0) RG_CMPI(1) "s_nop 0\n\t" RG_LEAVE(0) RG_LEAVE(1)
+                 RG_START(0) RG_START(1) RG_WAIT RG_HOLD(0) RG_HOLD(1)
+                 : RG_O_CHAIN(0), RG_O_CHAIN(1), RG_O_START(0), RG_O_START(1)
+                 : RG_I_CHAIN(0), RG_I_CHAIN(1), RG_I_START(0), RG_I_START(1), [sel] "s"(sel),
+                   [init] "s"(init), [idx] "n"(IDX)
+                 : "memory", "scc");
+  } else {
+    asm volatile(RG_PERM(0) RG_PERM(1) RG_READ(0) RG_READ(1) RG_VALID(0) RG_VALID(1)
+                 RG_WAIT "s_nop 0\n\t" RG_HOLD(0) RG_HOLD(1)
+                 : RG_O_CHAIN(0), RG_O_CHAIN(1)
+                 : RG_I_CHAIN(0), RG_I_CHAIN(1), [sel] "s"(sel), [idx] "n"(IDX)
+                 : "memory");
+  }
+  s[0] = t[0];
+  s[1] = t[1];
+}
+
+template <int MODE, int Q>
+__device__ __forceinline__ void raggedWalk16(const uint4 (&piece)[2], uint32_t (&s)[2],
+                                             const uint32_t (&rem)[2], StreamBook (&b)[2],
+                                             uint64_t (&mA)[2], uint64_t (&mB)[2],
+                                             uint64_t (&vA)[2], uint64_t (&vB)[2], uint32_t T,
+                                             uint32_t init) {
+  uint32_t w[2];
+#define RG_WORD(K, FIELD)                                                                     \
+  w[0] = piece[0].FIELD;                                                                      \
+  w[1] = piece[1].FIELD;                                                                      \
+  raggedStep<MODE, 16 * Q + 4 * K + 0>(s, w, rem, b, mA, mB, vA, vB, 0x0c0c0400u, T, init);   \
+  raggedStep<MODE, 16 * Q + 4 * K + 1>(s, w, rem, b, mB, mA, vB, vA, 0x0c0c0401u, T, init);   \
+  raggedStep<MODE, 16 * Q + 4 * K + 2>(s, w, rem, b, mA, mB, vA, vB, 0x0c0c0402u, T, init);   \
+  raggedStep<MODE, 16 * Q + 4 * K + 3>(s, w, rem, b, mB, mA, vB, vA, 0x0c0c0403u, T, init);
+  RG_WORD(0, x) RG_WORD(1, y) RG_WORD(2, z) RG_WORD(3, w)
+#undef RG_WORD
+}
+
+__device__ __forceinline__ uint32_t waveMaxU32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const uint32_t other = uint32_t(__shfl_xor(int(v), o, 64));
+    v = other > v ? other : v;
+  }
+  return uint32_t(__builtin_amdgcn_readfirstlane(int(v)));
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kStreamThreads)
+k_ragged(DevDfa d, Batch io) {
+  constexpr int CH = kStreamChains;
+  constexpr int THREADS = kStreamThreads;
+  constexpr bool kAcc = MODE == kSmLastStartEnd || MODE == kSmLastEnd;
+  constexpr bool kStart = MODE == kSmLastStartEnd || MODE == kSmFullStart;
+  __shared__ __align__(16) uint8_t lds[kStreamTabBytes + 1024];  // table at LDS offset 0
+  uint8_t *tab = lds;
+  int32_t *ldsRes = reinterpret_cast<int32_t *>(lds + kStreamTabBytes);
+
+  const uint32_t init = d.init, firstAccept = d.firstAccept;
+  const uint64_t linesPerTile = uint64_t(THREADS) * CH;
+  const uint64_t nTiles = (io.n + linesPerTile - 1) / linesPerTile;
+  if (blockIdx.x >= nTiles) return;
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(d.table);
+    const uint32_t n16 = d.tableBytes / 16;
+    uint4 v[kStreamTabBytes / 16 / THREADS];
+#pragma unroll
+    for (uint32_t k = 0; k < kStreamTabBytes / 16 / THREADS; ++k) {
+      const uint32_t i = k * THREADS + threadIdx.x;
+      v[k] = i < n16 ? src[i] : make_uint4(0, 0, 0, 0);
+    }
+    const int32_t myRes = threadIdx.x < d.nStates ? d.result[threadIdx.x] : 0;
+    uint4 *dst = reinterpret_cast<uint4 *>(tab);
+#pragma unroll
+    for (uint32_t k = 0; k < kStreamTabBytes / 16 / THREADS; ++k) dst[k * THREADS + threadIdx.x] = v[k];
+    if (threadIdx.x < 256) ldsRes[threadIdx.x] = myRes;
+  }
+  __syncthreads();
+
+  const uint64_t total = io.offsets[io.n];
+  if (total < 64) return;  // every line is a "tail" line: k_generic takes them all
+  const int32_t initResult = init >= firstAccept ? ldsRes[init] : 0;
+
+  for (uint64_t tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+    const uint8_t *base[CH];
+    uint32_t len[CH], lastBlk[CH];
+    uint64_t ln[CH];
+    bool mine[CH];
+    uint32_t blocksWanted = 0;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      ln[c] = tile * linesPerTile + uint64_t(c) * THREADS + threadIdx.x;
+      uint64_t o = 0, e = 0;
+      mine[c] = false;
+      if (ln[c] < io.n) {
+        o = io.offsets[ln[c]];
+        e = io.offsets[ln[c] + 1];
+        mine[c] = e + 64 <= total;  // else: a tail line, left to k_generic (Batch::tailOnly)
+      }
+      if (!mine[c]) { o = 0; e = 0; }  // idle lane: reads the buffer's first block, stores nothing
+      base[c] = io.data + o;
+      len[c] = uint32_t(e - o);
+      const uint32_t nb = (len[c] + 63u) >> 6;
+      lastBlk[c] = nb ? nb - 1 : 0;
+      blocksWanted = nb > blocksWanted ? nb : blocksWanted;
+    }
+    const uint32_t R = waveMaxU32(blocksWanted);  // this WAVE's trip count
+
+    uint32_t s[CH], accS[CH], endv[CH], startv[CH];
+    uint64_t mA[CH], mB[CH], vA[CH], vB[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      s[c] = init; accS[c] = 0; endv[c] = 0; startv[c] = 0;
+      mA[c] = ~0ull; mB[c] = ~0ull; vA[c] = ~0ull; vB[c] = ~0ull;
+    }
+
+    BlockRegs<1> A[CH], B[CH];
+    auto issue = [&](BlockRegs<1> (&blk)[CH], uint32_t r) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const uint32_t rr = r < lastBlk[c] ? r : lastBlk[c];
+          blk[c].p[k] = *reinterpret_cast<const uint4 *>(base[c] + uint64_t(rr) * 64 + 16 * k);
+        }
+      }
+    };
+    auto walk = [&](const BlockRegs<1> (&blk)[CH], uint32_t r) {
+      uint32_t rem[CH];
+      StreamBook b[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const uint32_t done = r * 64;
+        rem[c] = len[c] > done ? (len[c] - done > 64 ? 64 : len[c] - done) : 0;
+        b[c].acc = accS[c]; b[c].end = 0; b[c].start = 0;
+      }
+      uint4 piece[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[0];
+      raggedWalk16<MODE, 0>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[1];
+      raggedWalk16<MODE, 1>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[2];
+      raggedWalk16<MODE, 2>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[3];
+      raggedWalk16<MODE, 3>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
+      // fold (as k_stream); the state after the block's 64th byte counts only if that byte
+      // was part of the line (rem == 64) - vA holds "step 63 was valid" for exactly that
+      const uint32_t off = r * 64;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const bool full = rem[c] == 64;
+        if (kAcc) {
+          accS[c] = b[c].acc;
+          endv[c] = b[c].end ? off + b[c].end : endv[c];
+          if (full && s[c] >= firstAccept) { accS[c] = s[c]; endv[c] = off + 64; }
+        }
+        if (kStart) {
+          startv[c] = b[c].start ? off + b[c].start - 1 : startv[c];
+          const bool wasInit63 = (mA[c] >> (threadIdx.x & 63)) & 1;
+          if (full && wasInit63 && s[c] != init) startv[c] = off + 63;
+        }
+      }
+    };
+
+    if (R) issue(A, 0);
+    for (uint32_t r = 0; r < R; r += 2) {
+      issue(B, r + 1);
+      walk(A, r);
+      issue(A, r + 2);
+      if (r + 1 < R) walk(B, r + 1);
+    }
+
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (!mine[c]) continue;
+      int32_t rr;
+      uint32_t en;
+      if (len[c] == 0) {
+        rr = initResult;  // no byte walked: the start state's own result, positions 0
+        en = 0;
+        startv[c] = 0;
+      } else if (kAcc) {
+        rr = endv[c] ? ldsRes[accS[c]] : 0;
+        en = endv[c];
+      } else {
+        rr = s[c] >= firstAccept ? ldsRes[s[c]] : 0;
+        en = len[c];
+      }
+      io.result[ln[c]] = rr;
+      if (io.end) io.end[ln[c]] = rr ? uint64_t(en) : 0;
+      if (kStart && io.start) io.start[ln[c]] = rr ? uint64_t(startv[c]) : 0;
+    }
+  }
+}
+
+#undef RG_PERM
+#undef RG_READ
+#undef RG_VALID
+#undef RG_CMPA
+#undef RG_CMPI
+#undef RG_ACC
+#undef RG_MEND
+#undef RG_END
+#undef RG_LEAVE
+#undef RG_START
+#undef RG_WAIT
+#undef RG_HOLD
+#undef RG_O_CHAIN
+#undef RG_O_ACC
+#undef RG_O_START
+#undef RG_I_CHAIN
+#undef RG_I_ACC
+#undef RG_I_START
+
+template <int MODE>
+hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
+                         hipStream_t stream) {
+  const uint64_t linesPerTile = uint64_t(kStreamThreads) * kStreamChains;
+  const uint64_t tiles = (b.n + linesPerTile - 1) / linesPerTile;
+  const uint64_t blocks = tiles < uint64_t(cfg.numCUs) ? tiles : uint64_t(cfg.numCUs);
+  hipLaunchKernelGGL(k_ragged<MODE>, dim3(uint32_t(blocks)), dim3(kStreamThreads), 0, stream, d, b);
+  return hipGetLastError();
+}

@@ -35,6 +35,7 @@ struct Batch {
   int32_t  *result;
   uint64_t *start;         // may be nullptr
   uint64_t *end;           // may be nullptr
+  uint32_t tailOnly = 0;   // k_generic: only lines ending within the buffer's last 64 bytes
 };
 
 struct LaunchCfg {

@@ -339,8 +339,13 @@ k_generic(DevDfa d, Batch b, int verb, int style, int lead) {
     uint64_t n;
     if (b.offsets) {
       const uint64_t o = b.offsets[line];
+      const uint64_t e = b.offsets[line + 1];
+      if (b.tailOnly) {  // the lines k_ragged leaves behind (see k_ragged.h)
+        const uint64_t total = b.offsets[b.n];
+        if (total >= 64 && e + 64 <= total) continue;
+      }
       p = b.data + o;
-      n = b.offsets[line + 1] - o;
+      n = e - o;
     } else {
       p = b.data + line * b.stride;
       n = b.stride;
@@ -543,6 +548,7 @@ k_leader_filter(DevDfa d, Batch b) {
 }
 
 #include "k_stream.h"
+#include "k_ragged.h"
 
 // Red::collect (lib/Red.cpp:103-116): all non-overlapping matches of a line, in order, by
 // repeated search<styLast,false> from the end of the previous match.  One line per lane.
@@ -759,6 +765,30 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
       return hipGetLastError();
     }
     return hipSuccess;
+  }
+
+  // Ragged lines, fused-u8 table, styles Last / Full of check / match, no leader to honour:
+  // k_ragged walks every line that ends >= 64 bytes before the end of the buffer, k_generic
+  // (tailOnly) the few that do not.
+  const bool raggedOk = !cfg.forceGeneric && fastPathEligible(d) && b.offsets &&
+                        (verb == kCheck || verb == kMatch) &&
+                        (style == kStyLast || style == kStyFull) && !lead &&
+                        d.tableBytes <= kStreamTabBytes && d.nStates <= 256;
+  if (raggedOk) {
+    hipError_t e;
+    Batch sb = b;
+    if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
+    if (style == kStyLast) {
+      if (sb.start) { *kernelName = "k_ragged<last,start,end>"; e = launchRaggedT<kSmLastStartEnd>(d, sb, cfg, stream); }
+      else { *kernelName = "k_ragged<last,end>"; e = launchRaggedT<kSmLastEnd>(d, sb, cfg, stream); }
+    } else {
+      if (sb.start) { *kernelName = "k_ragged<full,start>"; e = launchRaggedT<kSmFullStart>(d, sb, cfg, stream); }
+      else { *kernelName = "k_ragged<full>"; e = launchRaggedT<kSmFull>(d, sb, cfg, stream); }
+    }
+    if (e != hipSuccess) return e;
+    Batch tb = b;
+    tb.tailOnly = 1;
+    return launchGeneric<REDGPU_TAB_LDS_FUSED_U8>(d, tb, verb, style, 0, cfg, stream);
   }
 
   *kernelName = "k_generic";

@@ -335,3 +335,40 @@ def test_collect_on_gpu():
     counts, res, st, en = one_amd.collect_batch(exe, unb64(kat["text"]), 2,
                                                 offsets=[0, len(unb64(kat["text"]))])
     assert int(counts[0]) == 5 and res[0].tolist() == [1, 4] and en[0].tolist() == [11, 16]
+
+
+@pytest.mark.parametrize("name", ["syn256", "uri", "dotstar_err", "newyork"])
+def test_ragged_stream_kernel_tail_and_shapes(name):
+    """k_ragged + its k_generic tail pass: lines ending inside the buffer's last 64 bytes, runs
+    of empty lines (also at the very end), buffers shorter than one block, block-multiple and
+    block-multiple+-1 lengths, one very long line among short ones."""
+    blob = load_dfa(name)
+    exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
+    rng = np.random.default_rng(11)
+    shapes = [
+        [0, 0, 0],                                   # nothing but empty lines
+        [5],                                         # total < 64
+        [63, 64, 65, 127, 128, 129, 0, 1, 200],      # around block multiples
+        [300] + [3] * 40 + [0] * 70,                 # long line first, empties at the end
+        list(rng.integers(0, 90, 3000)) + [0, 0, 1, 2, 0],
+        [64] * 2050,                                 # whole blocks, > one tile
+        [5000] + list(rng.integers(0, 40, 1500)),    # one line far longer than its wave-mates
+    ]
+    for lens in shapes:
+        offsets = np.zeros(len(lens) + 1, dtype=np.uint64)
+        offsets[1:] = np.cumsum(lens)
+        total = int(offsets[-1])
+        data = (W.fixed_lines(1, max(total, 1), 21, alphabet=(name != "syn256"),
+                              plant=b"x New York http://a.bc/ error " if name != "syn256" else None,
+                              plant_every=1, plant_at=0)[:total])
+        for si in (4, 5):
+            er, es, ee = cpu.batch("match", si, 0, data, offsets=offsets)
+            r, s, e = one_amd.match_batch(exe, data, si, 0, offsets=offsets)
+            assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee), \
+                (name, si, lens[:8])
+            r2, _, e2 = one_amd.match_batch(exe, data, si, 0, offsets=offsets, want_start=False)
+            assert np.array_equal(r2, er) and np.array_equal(e2, ee)
+            assert np.array_equal(one_amd.check_batch(exe, data, si, 0, offsets=offsets),
+                                  cpu.batch("check", si, 0, data, offsets=offsets)[0])
+    one_amd.match_batch(exe, data, 4, 0, offsets=offsets)
+    assert one_amd.last_kernel().startswith("k_ragged")

@@ -138,6 +138,30 @@ int redgpu_collect_batch(const redgpu_dfa *dfa, const uint8_t *data, const uint6
                          uint64_t stride, uint64_t n, uint64_t cap, uint64_t *counts,
                          int32_t *result, uint64_t *start, uint64_t *end);
 
+/*   redgpu_match_all_batch <-> matchAll(exec, string_view, vector<Outcome>&)  include/Matcher.h:127,
+ *                              lib/Matcher.cpp:97-102, core include/Matcher.h:711-766 (also
+ *                              Red::allMatches, lib/Red.cpp:713-715): ONE anchored walk per line
+ *                              reporting every maximal run of bytes with the same accepted result
+ *                              (RE2::Set::Match style).  The reference's public entry always
+ *                              runs with doLeader = true: pass do_leader = 1 for parity with it.
+ *                              Record layout and counts[] exactly as redgpu_collect_batch. */
+int redgpu_match_all_batch(const redgpu_dfa *dfa, int do_leader, const uint8_t *data,
+                           const uint64_t *offsets, uint64_t stride, uint64_t n, uint64_t cap,
+                           uint64_t *counts, int32_t *result, uint64_t *start, uint64_t *end);
+
+/*   redgpu_advance_batch <-> StatefulMatcher (include/Matcher.h:770-792, lib/Matcher.cpp:106-158),
+ *                            n independent matchers advanced by one CHUNK each: state[i] is
+ *                            matcher i's state_ on entry and on return (an opaque token, valid
+ *                            only with the handle that produced it; REDGPU_STATE_INITIAL = a
+ *                            freshly constructed StatefulMatcher - a buffer memset to 0xff is n
+ *                            fresh matchers), result[i] = result() after the chunk's last byte.
+ *                            Feeding a stream in chunks of any sizes gives the same states and
+ *                            results as advance() byte by byte: inputs larger than device memory
+ *                            are walked chunk by chunk. */
+#define REDGPU_STATE_INITIAL 0xffffffffu
+int redgpu_advance_batch(const redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,
+                         uint64_t stride, uint64_t n, uint32_t *state, int32_t *result);
+
 /* ---- the same verbs over DEVICE-resident buffers, asynchronous on `stream` ---------------
  * data/offsets/result/start/end are device pointers on the handle's device; `stream` is a
  * hipStream_t (NULL = the default stream).  Nothing is allocated, copied or synchronised. */
@@ -157,6 +181,15 @@ int redgpu_search_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, con
 int redgpu_collect_batch_dev(const redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,
                              uint64_t stride, uint64_t n, uint64_t cap, uint64_t *counts,
                              int32_t *result, uint64_t *start, uint64_t *end, void *stream);
+
+int redgpu_match_all_batch_dev(const redgpu_dfa *dfa, int do_leader, const uint8_t *data,
+                               const uint64_t *offsets, uint64_t stride, uint64_t n,
+                               uint64_t cap, uint64_t *counts, int32_t *result, uint64_t *start,
+                               uint64_t *end, void *stream);
+
+int redgpu_advance_batch_dev(const redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,
+                             uint64_t stride, uint64_t n, uint32_t *state, int32_t *result,
+                             void *stream);
 
 /* Name of the kernel the last *_batch* call on this thread launched (for profiles), or "". */
 const char *redgpu_last_kernel(void);

@@ -232,6 +232,71 @@ void searchBatch(const Executable &exec, const Byte *data, const uint64_t *offse
                                    start, end));
 }
 
+namespace detail {
+// the two list verbs: first try with room for 16 records, retry once with the exact count
+template <class F>
+size_t listOne(F call, const Executable &exec, std::string_view sv, std::vector<Outcome> &out) {
+  const uint64_t off[2] = {0, sv.size()};
+  uint64_t cap = 16, found = 0;
+  std::vector<Result> r;
+  std::vector<uint64_t> s, e;
+  for (int pass = 0; pass < 2; ++pass) {
+    r.assign(cap, 0);
+    s.assign(cap, 0);
+    e.assign(cap, 0);
+    throwOnError(call(exec.handle(), reinterpret_cast<const Byte *>(sv.data()), off, cap, &found,
+                      r.data(), s.data(), e.data()));
+    if (found <= cap) break;
+    cap = found;
+  }
+  out.clear();
+  for (uint64_t i = 0; i < found; ++i) out.push_back(Outcome{r[i], size_t(s[i]), size_t(e[i])});
+  return out.size();
+}
+} // namespace detail
+
+// matchAll(exec, sv, out): include/Matcher.h:127, lib/Matcher.cpp:97-102 (doLeader = true)
+inline size_t matchAll(const Executable &exec, std::string_view sv, std::vector<Outcome> &out) {
+  return detail::listOne(
+      [](const redgpu_dfa *h, const Byte *p, const uint64_t *off, uint64_t cap, uint64_t *cnt,
+         Result *r, uint64_t *s, uint64_t *e) {
+        return redgpu_match_all_batch(h, 1, p, off, 0, 1, cap, cnt, r, s, e);
+      },
+      exec, sv, out);
+}
+
+// Red::collect(text, out): include/Red.h:115, lib/Red.cpp:103-116
+inline size_t collect(const Executable &exec, std::string_view sv, std::vector<Outcome> &out) {
+  return detail::listOne(
+      [](const redgpu_dfa *h, const Byte *p, const uint64_t *off, uint64_t cap, uint64_t *cnt,
+         Result *r, uint64_t *s, uint64_t *e) {
+        return redgpu_collect_batch(h, p, off, 0, 1, cap, cnt, r, s, e);
+      },
+      exec, sv, out);
+}
+
+// StatefulMatcher: include/Matcher.h:770-792.  advance(Byte) as in the reference, plus
+// advance(ptr, len) for a whole chunk per launch.  exec must outlive this object.
+class StatefulMatcher {
+public:
+  explicit StatefulMatcher(const Executable &exec) : exec_(exec) { advance(nullptr, 0); }
+
+  Result advance(Byte input) { return advance(&input, 1); }
+  Result advance(const Byte *p, size_t len) {
+    const uint64_t off[2] = {0, len};
+    const Byte dummy = 0;
+    throwOnError(redgpu_advance_batch(exec_.handle(), p ? p : &dummy, off, 0, 1, &state_,
+                                      &result_));
+    return result_;
+  }
+  Result result() const { return result_; }
+
+private:
+  const Executable &exec_;
+  uint32_t state_ = REDGPU_STATE_INITIAL;
+  Result result_ = 0;
+};
+
 // run-time style: doLeader = true, unknown style -> RedExceptExec("unsupported style")
 // (lib/Matcher.cpp:37-67)
 inline Result check(const Executable &exec, std::string_view sv, Style style) {

@@ -104,6 +104,15 @@ def lib() -> C.CDLL:
         l.redgpu_collect_batch.argtypes = [vp, vp, vp, u64, u64, u64, vp, vp, vp, vp]
         l.redgpu_collect_batch_dev.restype = C.c_int
         l.redgpu_collect_batch_dev.argtypes = [vp, vp, vp, u64, u64, u64, vp, vp, vp, vp, vp]
+        l.redgpu_match_all_batch.restype = C.c_int
+        l.redgpu_match_all_batch.argtypes = [vp, i32, vp, vp, u64, u64, u64, vp, vp, vp, vp]
+        l.redgpu_match_all_batch_dev.restype = C.c_int
+        l.redgpu_match_all_batch_dev.argtypes = [vp, i32, vp, vp, u64, u64, u64, vp, vp, vp, vp,
+                                                 vp]
+        l.redgpu_advance_batch.restype = C.c_int
+        l.redgpu_advance_batch.argtypes = [vp, vp, vp, u64, u64, vp, vp]
+        l.redgpu_advance_batch_dev.restype = C.c_int
+        l.redgpu_advance_batch_dev.argtypes = [vp, vp, vp, u64, u64, vp, vp, vp]
         _lib = l
     return _lib
 

@@ -33,6 +33,8 @@ enum StreamMode : int {
   kSmLastEnd = 1,       // match<styLast>  result + end; also check<styLast> (end not stored)
   kSmFullStart = 3,     // match<styFull>  result + start (+ end = line length)
   kSmFull = 4,          // check<styFull> / match<styFull> without start
+  kSmAdvance = 5,       // StatefulMatcher chunk: kSmFull's walk, state[] read at the first block
+                        // of a line and written back after the last (include/Matcher.h:770-792)
 };
 
 struct StreamBook {
@@ -131,6 +133,7 @@ __device__ __forceinline__ void streamWalk16(const uint4 (&piece)[2], uint32_t (
 template <int HALVES>
 struct BlockRegs {
   uint4 p[4 * HALVES];
+  uint32_t st;  // kSmAdvance: the line's entry state, requested with the block (else unused)
 };
 
 // HALVES = 2: 128-byte blocks (stride % 128 == 0); HALVES = 1: 64-byte blocks (stride % 64 == 0)
@@ -192,6 +195,16 @@ k_stream(DevDfa d, Batch io) {
 #pragma unroll
       for (int c = 0; c < CH; ++c) b[c].p[k] = reinterpret_cast<const uint4 *>(p[c])[k];
     }
+    if (MODE == kSmAdvance) {
+      // unconditional like the data (every block re-requests its line's state; only the first
+      // block of a line uses it) so the in-order vmcnt counts stay exact
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        uint64_t ln = t * linesPerTile + uint64_t(c) * THREADS + threadIdx.x;
+        if (ln >= io.n) ln = io.n - 1;
+        b[c].st = io.state[ln];
+      }
+    }
     if (ldQ < Q) {
       ++ldQ;
       if (++ldR == R) { ldR = 0; ldTile += G; }
@@ -211,6 +224,7 @@ k_stream(DevDfa d, Batch io) {
       for (int c = 0; c < CH; ++c) {
         s[c] = init; accS[c] = 0; endv[c] = 0; startv[c] = 0;
         mA[c] = ~0ull; mB[c] = ~0ull;
+        if (MODE == kSmAdvance) s[c] = blk[c].st < d.nStates ? blk[c].st : init;
       }
     }
 #pragma unroll
@@ -262,6 +276,7 @@ k_stream(DevDfa d, Batch io) {
             en = lineLen;
           }
           io.result[ln] = rr;
+          if (MODE == kSmAdvance) io.state[ln] = s[c];
           if (io.end) io.end[ln] = rr ? uint64_t(en) : 0;
           if (kStart && io.start) io.start[ln] = rr ? uint64_t(startv[c]) : 0;
         }

@@ -36,6 +36,7 @@ struct Batch {
   uint64_t *start;         // may be nullptr
   uint64_t *end;           // may be nullptr
   uint32_t tailOnly = 0;   // k_generic: only lines ending within the buffer's last 64 bytes
+  uint32_t *state = nullptr; // advance only: per-line StatefulMatcher state, in/out
 };
 
 struct LaunchCfg {
@@ -52,6 +53,15 @@ hipError_t launchBatch(const DevDfa &dfa, const Batch &b, int verb, int style, i
 // [line*cap, line*cap+cap) of result/start/end, counts[line] = number found.
 hipError_t launchCollect(const DevDfa &dfa, const Batch &b, uint64_t cap, uint64_t *counts,
                          const LaunchCfg &cfg, hipStream_t stream);
+
+// matchAll per line (include/Matcher.h:711-766): same record layout as launchCollect.
+hipError_t launchMatchAll(const DevDfa &dfa, const Batch &b, uint64_t cap, uint64_t *counts,
+                          int doLeader, const LaunchCfg &cfg, hipStream_t stream);
+
+// StatefulMatcher::advance over one chunk per line (include/Matcher.h:770-792):
+// state[line] in/out (device state index, >= nStates means "fresh matcher"), b.result out.
+hipError_t launchAdvance(const DevDfa &dfa, const Batch &b, uint32_t *state, const LaunchCfg &cfg,
+                         hipStream_t stream, const char **kernelName);
 
 // True when the specialised fixed-stride kernels can run this DFA at all.
 bool fastPathEligible(const DevDfa &dfa);

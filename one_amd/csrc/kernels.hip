@@ -599,6 +599,129 @@ k_collect(DevDfa d, Batch b, uint64_t cap, uint64_t *counts) {
   }
 }
 
+// matchAllCore (include/Matcher.h:711-766; public entry matchAll, lib/Matcher.cpp:97-102, which
+// instantiates <styTangent, doLeader = true>): ONE anchored walk that reports every maximal run
+// of bytes over which the accepted result stays the same - a la RE2::Set::Match.  A run's end_
+// grows while the same result repeats (:747-748); a different positive result opens a new
+// record (:749-752); a non-accepting byte resets the run (:757) and a pure dead end stops the
+// walk (:755-756).  The record being extended keeps its end in a register and is flushed when
+// the run closes, instead of re-storing it per byte.
+template <class T>
+__device__ uint64_t matchAllLane(const T &tab, const LaneCtx &c, const uint8_t *p, uint64_t n,
+                                 bool lead, uint64_t cap, int32_t *res, uint64_t *st,
+                                 uint64_t *en) {
+  if (lead && !lookingAt(c, p, 0, n)) return 0;
+  uint32_t s = c.init;
+  int32_t prev = 0;
+  uint64_t matchStart = 0, found = 0, curEnd = 0;
+  walkBytes(p, 0, n, [&](uint32_t byte, uint64_t idx) {
+    const uint32_t was = s;
+    s = tab.next(s, byte);
+    if (was == c.init && s != was) matchStart = idx;
+    if (s >= c.firstAccept) {
+      const int32_t r = c.res[s];
+      if (r != prev) {
+        if (found && found - 1 < cap && en) en[found - 1] = curEnd;
+        prev = r;
+        if (found < cap) {
+          res[found] = r;
+          if (st) st[found] = matchStart;
+        }
+        ++found;
+      }
+      curEnd = idx + 1;
+    } else {
+      if (s < c.nPureDead) return false;
+      prev = 0;
+    }
+    return true;
+  });
+  if (found && found - 1 < cap && en) en[found - 1] = curEnd;
+  return found;
+}
+
+template <int KIND, int kThreads>
+__global__ void __launch_bounds__(kThreads)
+k_matchall(DevDfa d, Batch b, uint64_t cap, uint64_t *counts, int lead) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  uint8_t *eq = lds;
+  uint8_t *leader = lds + 256;
+  uint8_t *ldsTab = lds + 512;
+  for (uint32_t i = threadIdx.x; i < 512 / 4; i += kThreads)
+    reinterpret_cast<uint32_t *>(lds)[i] = reinterpret_cast<const uint32_t *>(d.equivLeader)[i];
+  if (Tab<KIND>::kInLds) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(d.table);
+    uint4 *dst = reinterpret_cast<uint4 *>(ldsTab);
+    for (uint32_t i = threadIdx.x; i < d.tableBytes / 16; i += kThreads) dst[i] = src[i];
+  }
+  __syncthreads();
+  const Tab<KIND> tab(Tab<KIND>::kInLds ? ldsTab : d.table, eq, d.nClasses);
+  LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
+            d.leaderLen};
+  const uint64_t step = uint64_t(gridDim.x) * kThreads;
+  for (uint64_t line = uint64_t(blockIdx.x) * kThreads + threadIdx.x; line < b.n; line += step) {
+    const uint8_t *p;
+    uint64_t n;
+    if (b.offsets) {
+      const uint64_t o = b.offsets[line];
+      p = b.data + o;
+      n = b.offsets[line + 1] - o;
+    } else {
+      p = b.data + line * b.stride;
+      n = b.stride;
+    }
+    counts[line] = matchAllLane(tab, c, p, n, lead != 0, cap, b.result + line * cap,
+                                b.start ? b.start + line * cap : nullptr,
+                                b.end ? b.end + line * cap : nullptr);
+  }
+}
+
+// StatefulMatcher::advance (include/Matcher.h:770-792, lib/Matcher.cpp:106-158) over a whole
+// chunk per line: state[line] is the matcher's state_ (a device state index; REDGPU_STATE_INITIAL
+// = a freshly constructed matcher, lib/Matcher.cpp:113-136), advanced by every byte of the
+// chunk with no early exit and no style rules, then stored back; result[line] = result() after
+// the last byte (= the state's result; for an empty chunk the current state's).
+template <int KIND, int kThreads>
+__global__ void __launch_bounds__(kThreads)
+k_advance(DevDfa d, Batch b, uint32_t *state) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  uint8_t *eq = lds;
+  uint8_t *leader = lds + 256;
+  uint8_t *ldsTab = lds + 512;
+  for (uint32_t i = threadIdx.x; i < 512 / 4; i += kThreads)
+    reinterpret_cast<uint32_t *>(lds)[i] = reinterpret_cast<const uint32_t *>(d.equivLeader)[i];
+  if (Tab<KIND>::kInLds) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(d.table);
+    uint4 *dst = reinterpret_cast<uint4 *>(ldsTab);
+    for (uint32_t i = threadIdx.x; i < d.tableBytes / 16; i += kThreads) dst[i] = src[i];
+  }
+  __syncthreads();
+  const Tab<KIND> tab(Tab<KIND>::kInLds ? ldsTab : d.table, eq, d.nClasses);
+  LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
+            d.leaderLen};
+  const uint64_t step = uint64_t(gridDim.x) * kThreads;
+  for (uint64_t line = uint64_t(blockIdx.x) * kThreads + threadIdx.x; line < b.n; line += step) {
+    const uint8_t *p;
+    uint64_t n;
+    if (b.offsets) {
+      const uint64_t o = b.offsets[line];
+      p = b.data + o;
+      n = b.offsets[line + 1] - o;
+    } else {
+      p = b.data + line * b.stride;
+      n = b.stride;
+    }
+    uint32_t s = state[line];
+    if (s >= d.nStates) s = d.init;  // REDGPU_STATE_INITIAL (and any token that is not ours)
+    walkBytes(p, 0, n, [&](uint32_t byte, uint64_t) {
+      s = tab.next(s, byte);
+      return true;
+    });
+    state[line] = s;
+    b.result[line] = c.resultOf(s);
+  }
+}
+
 template <class K>
 hipError_t setLds(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return hipSuccess;
@@ -638,6 +761,40 @@ hipError_t launchCollectK(const DevDfa &d, const Batch &b, uint64_t cap, uint64_
   if (blocks == 0) blocks = 1;
   hipLaunchKernelGGL((k_collect<KIND, kThreads>), dim3(uint32_t(blocks)), dim3(kThreads), ldsBytes,
                      stream, d, b, cap, counts);
+  return hipGetLastError();
+}
+
+template <int KIND>
+hipError_t launchMatchAllK(const DevDfa &d, const Batch &b, uint64_t cap, uint64_t *counts,
+                           int lead, const LaunchCfg &cfg, hipStream_t stream) {
+  constexpr int kThreads = Tab<KIND>::kInLds ? 1024 : 256;
+  const size_t ldsBytes = 512 + (Tab<KIND>::kInLds ? size_t(d.tableBytes) : 0);
+  hipError_t e = setLds(k_matchall<KIND, kThreads>, ldsBytes);
+  if (e != hipSuccess) return e;
+  uint64_t blocks = (b.n + kThreads - 1) / kThreads;
+  const uint64_t perCu = Tab<KIND>::kInLds ? (ldsBytes <= 80 * 1024 ? 2 : 1) : 8;
+  const uint64_t capBlocks = uint64_t(cfg.numCUs) * perCu;
+  if (blocks > capBlocks) blocks = capBlocks;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL((k_matchall<KIND, kThreads>), dim3(uint32_t(blocks)), dim3(kThreads),
+                     ldsBytes, stream, d, b, cap, counts, lead);
+  return hipGetLastError();
+}
+
+template <int KIND>
+hipError_t launchAdvanceK(const DevDfa &d, const Batch &b, uint32_t *state, const LaunchCfg &cfg,
+                          hipStream_t stream) {
+  constexpr int kThreads = Tab<KIND>::kInLds ? 1024 : 256;
+  const size_t ldsBytes = 512 + (Tab<KIND>::kInLds ? size_t(d.tableBytes) : 0);
+  hipError_t e = setLds(k_advance<KIND, kThreads>, ldsBytes);
+  if (e != hipSuccess) return e;
+  uint64_t blocks = (b.n + kThreads - 1) / kThreads;
+  const uint64_t perCu = Tab<KIND>::kInLds ? (ldsBytes <= 80 * 1024 ? 2 : 1) : 8;
+  const uint64_t capBlocks = uint64_t(cfg.numCUs) * perCu;
+  if (blocks > capBlocks) blocks = capBlocks;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL((k_advance<KIND, kThreads>), dim3(uint32_t(blocks)), dim3(kThreads),
+                     ldsBytes, stream, d, b, state);
   return hipGetLastError();
 }
 
@@ -707,6 +864,45 @@ hipError_t launchCollect(const DevDfa &d, const Batch &b, uint64_t cap, uint64_t
   default:
     return launchCollectK<REDGPU_TAB_GLOBAL_U32>(d, b, cap, counts, cfg, stream);
   }
+}
+
+#define REDGPU_KIND_SWITCH(CALL)                                                          \
+  switch (d.tableKind) {                                                                  \
+  case REDGPU_TAB_LDS_FUSED_U8: return CALL(REDGPU_TAB_LDS_FUSED_U8);                     \
+  case REDGPU_TAB_LDS_FUSED_U16: return CALL(REDGPU_TAB_LDS_FUSED_U16);                   \
+  case REDGPU_TAB_LDS_CLASS_U16: return CALL(REDGPU_TAB_LDS_CLASS_U16);                   \
+  case REDGPU_TAB_GLOBAL_U16: return CALL(REDGPU_TAB_GLOBAL_U16);                         \
+  default: return CALL(REDGPU_TAB_GLOBAL_U32);                                            \
+  }
+
+hipError_t launchMatchAll(const DevDfa &d, const Batch &b, uint64_t cap, uint64_t *counts,
+                          int doLeader, const LaunchCfg &cfg, hipStream_t stream) {
+  if (b.n == 0) return hipSuccess;
+  const int lead = doLeader && d.leaderLen > 0;
+#define MA_CALL(K) launchMatchAllK<K>(d, b, cap, counts, lead, cfg, stream)
+  REDGPU_KIND_SWITCH(MA_CALL)
+#undef MA_CALL
+}
+
+hipError_t launchAdvance(const DevDfa &d, const Batch &b, uint32_t *state, const LaunchCfg &cfg,
+                         hipStream_t stream, const char **kernelName) {
+  *kernelName = "k_advance";
+  if (b.n == 0) return hipSuccess;
+  // chunks that are whole 64-byte blocks at a fixed stride: the streaming kernel
+  if (!cfg.forceGeneric && fastPathEligible(d) && !b.offsets && b.stride >= 64 &&
+      b.stride % 64 == 0 && b.stride < (1ull << 31) &&
+      (reinterpret_cast<uintptr_t>(b.data) % 16) == 0 && d.tableBytes <= kStreamTabBytes &&
+      d.nStates <= 256) {
+    *kernelName = "k_stream<advance>";
+    Batch sb = b;
+    sb.state = state;
+    sb.start = nullptr;
+    sb.end = nullptr;
+    return launchStreamT<kSmAdvance>(d, sb, cfg, stream);
+  }
+#define AD_CALL(K) launchAdvanceK<K>(d, b, state, cfg, stream)
+  REDGPU_KIND_SWITCH(AD_CALL)
+#undef AD_CALL
 }
 
 hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int doLeader,

@@ -157,9 +157,12 @@ int runHost(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint
   return REDGPU_OK;
 }
 
-int collectDev(const redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets, uint64_t stride,
-               uint64_t n, uint64_t cap, uint64_t *counts, int32_t *result, uint64_t *start,
-               uint64_t *end, hipStream_t stream) {
+// the two verbs that emit a variable-length record list per line
+enum ListVerb : int { kListCollect = 0, kListMatchAll = 1, kListMatchAllLeader = 2 };
+
+int collectDev(const redgpu_dfa *dfa, int listVerb, const uint8_t *data, const uint64_t *offsets,
+               uint64_t stride, uint64_t n, uint64_t cap, uint64_t *counts, int32_t *result,
+               uint64_t *start, uint64_t *end, hipStream_t stream) {
   if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
   if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
   if (n == 0) return REDGPU_OK;
@@ -170,8 +173,11 @@ int collectDev(const redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offse
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   Batch b{data, offsets, stride, n, result, start, end};
   LaunchCfg cfg{dfa->numCUs, 0};
-  hipError_t e = launchCollect(dfa->dev, b, cap, counts, cfg, stream);
-  tlsKernel = "k_collect";
+  hipError_t e = listVerb == kListCollect
+                     ? launchCollect(dfa->dev, b, cap, counts, cfg, stream)
+                     : launchMatchAll(dfa->dev, b, cap, counts, listVerb == kListMatchAllLeader,
+                                      cfg, stream);
+  tlsKernel = listVerb == kListCollect ? "k_collect" : "k_matchall";
   if (e != hipSuccess) return failHip(e, "kernel launch");
   return REDGPU_OK;
 }
@@ -344,13 +350,38 @@ int redgpu_search_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, con
 int redgpu_collect_batch_dev(const redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,
                              uint64_t stride, uint64_t n, uint64_t cap, uint64_t *counts,
                              int32_t *result, uint64_t *start, uint64_t *end, void *stream) {
-  return collectDev(dfa, data, offsets, stride, n, cap, counts, result, start, end,
+  return collectDev(dfa, kListCollect, data, offsets, stride, n, cap, counts, result, start, end,
                     static_cast<hipStream_t>(stream));
 }
+
+int redgpu_match_all_batch_dev(const redgpu_dfa *dfa, int do_leader, const uint8_t *data,
+                               const uint64_t *offsets, uint64_t stride, uint64_t n,
+                               uint64_t cap, uint64_t *counts, int32_t *result, uint64_t *start,
+                               uint64_t *end, void *stream) {
+  return collectDev(dfa, do_leader ? kListMatchAllLeader : kListMatchAll, data, offsets, stride, n,
+                    cap, counts, result, start, end, static_cast<hipStream_t>(stream));
+}
+
+static int listHost(const redgpu_dfa *dfa, int listVerb, const uint8_t *data,
+                    const uint64_t *offsets, uint64_t stride, uint64_t n, uint64_t cap,
+                    uint64_t *counts, int32_t *result, uint64_t *start, uint64_t *end);
 
 int redgpu_collect_batch(const redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,
                          uint64_t stride, uint64_t n, uint64_t cap, uint64_t *counts,
                          int32_t *result, uint64_t *start, uint64_t *end) {
+  return listHost(dfa, kListCollect, data, offsets, stride, n, cap, counts, result, start, end);
+}
+
+int redgpu_match_all_batch(const redgpu_dfa *dfa, int do_leader, const uint8_t *data,
+                           const uint64_t *offsets, uint64_t stride, uint64_t n, uint64_t cap,
+                           uint64_t *counts, int32_t *result, uint64_t *start, uint64_t *end) {
+  return listHost(dfa, do_leader ? kListMatchAllLeader : kListMatchAll, data, offsets, stride, n,
+                  cap, counts, result, start, end);
+}
+
+static int listHost(const redgpu_dfa *dfa, int listVerb, const uint8_t *data,
+                    const uint64_t *offsets, uint64_t stride, uint64_t n, uint64_t cap,
+                    uint64_t *counts, int32_t *result, uint64_t *start, uint64_t *end) {
   if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
   if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
   if (n == 0) return REDGPU_OK;
@@ -383,7 +414,7 @@ int redgpu_collect_batch(const redgpu_dfa *dfa, const uint8_t *data, const uint6
     CH_TRY(hipMemcpy(dOff, offsets, (n + 1) * 8, hipMemcpyHostToDevice), "copy offsets");
   }
   if (total) CH_TRY(hipMemcpy(dData, data, total, hipMemcpyHostToDevice), "copy data");
-  rc = collectDev(dfa, dData, dOff, stride, n, cap, dCnt, dRes, dStart, dEnd, nullptr);
+  rc = collectDev(dfa, listVerb, dData, dOff, stride, n, cap, dCnt, dRes, dStart, dEnd, nullptr);
   if (rc != REDGPU_OK) { cleanup(); return rc; }
   CH_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
   CH_TRY(hipMemcpy(counts, dCnt, n * 8, hipMemcpyDeviceToHost), "copy counts");
@@ -393,6 +424,74 @@ int redgpu_collect_batch(const redgpu_dfa *dfa, const uint8_t *data, const uint6
     if (end) CH_TRY(hipMemcpy(end, dEnd, slots * 8, hipMemcpyDeviceToHost), "copy end");
   }
 #undef CH_TRY
+  cleanup();
+  return REDGPU_OK;
+}
+
+int redgpu_advance_batch_dev(const redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,
+                             uint64_t stride, uint64_t n, uint32_t *state, int32_t *result,
+                             void *stream) {
+  if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
+  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (n == 0) return REDGPU_OK;
+  if (!state) return fail(REDGPU_EAPI, "null state buffer");
+  if (!result) return fail(REDGPU_EAPI, "null result buffer");
+  if (!data && (offsets || stride)) return fail(REDGPU_EAPI, "null data buffer");
+  DeviceScope scope(dfa->device);
+  if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  Batch b{data, offsets, stride, n, result, nullptr, nullptr};
+  LaunchCfg cfg{dfa->numCUs, (dfa->flags & REDGPU_F_FORCE_GENERIC) ? 1 : 0};
+  const char *name = "";
+  hipError_t e = launchAdvance(dfa->dev, b, state, cfg, static_cast<hipStream_t>(stream), &name);
+  tlsKernel = name;
+  if (e != hipSuccess) return failHip(e, "kernel launch");
+  return REDGPU_OK;
+}
+
+int redgpu_advance_batch(const redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,
+                         uint64_t stride, uint64_t n, uint32_t *state, int32_t *result) {
+  if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
+  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (n == 0) return REDGPU_OK;
+  if (!state) return fail(REDGPU_EAPI, "null state buffer");
+  if (!result) return fail(REDGPU_EAPI, "null result buffer");
+  const uint64_t total = offsets ? offsets[n] : stride * n;
+  if (offsets) {
+    for (uint64_t i = 0; i < n; ++i)
+      if (offsets[i] > offsets[i + 1]) return fail(REDGPU_EAPI, "offsets not monotonic");
+  }
+  if (total && !data) return fail(REDGPU_EAPI, "null data buffer");
+  DeviceScope scope(dfa->device);
+  if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  uint8_t *dData = nullptr;
+  uint64_t *dOff = nullptr;
+  uint32_t *dState = nullptr;
+  int32_t *dRes = nullptr;
+  auto cleanup = [&]() {
+    for (void *q : {(void *)dData, (void *)dOff, (void *)dState, (void *)dRes})
+      if (q) (void)hipFree(q);
+  };
+  int rc = REDGPU_OK;
+#define AD_TRY(expr, what)                                                    \
+  do {                                                                        \
+    hipError_t e_ = (expr);                                                   \
+    if (e_ != hipSuccess) { rc = failHip(e_, what); cleanup(); return rc; }   \
+  } while (0)
+  AD_TRY(hipMalloc(reinterpret_cast<void **>(&dData), total + 16), "hipMalloc data");
+  AD_TRY(hipMalloc(reinterpret_cast<void **>(&dState), n * 4), "hipMalloc state");
+  AD_TRY(hipMalloc(reinterpret_cast<void **>(&dRes), n * 4), "hipMalloc result");
+  if (offsets) {
+    AD_TRY(hipMalloc(reinterpret_cast<void **>(&dOff), (n + 1) * 8), "hipMalloc offsets");
+    AD_TRY(hipMemcpy(dOff, offsets, (n + 1) * 8, hipMemcpyHostToDevice), "copy offsets");
+  }
+  if (total) AD_TRY(hipMemcpy(dData, data, total, hipMemcpyHostToDevice), "copy data");
+  AD_TRY(hipMemcpy(dState, state, n * 4, hipMemcpyHostToDevice), "copy state");
+  rc = redgpu_advance_batch_dev(dfa, dData, dOff, stride, n, dState, dRes, nullptr);
+  if (rc != REDGPU_OK) { cleanup(); return rc; }
+  AD_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  AD_TRY(hipMemcpy(state, dState, n * 4, hipMemcpyDeviceToHost), "copy state back");
+  AD_TRY(hipMemcpy(result, dRes, n * 4, hipMemcpyDeviceToHost), "copy result");
+#undef AD_TRY
   cleanup();
   return REDGPU_OK;
 }

@@ -253,6 +253,106 @@ def collect(exe, text: bytes, cap: int = 64):
     return [(int(res[0, i]), int(st[0, i]), int(en[0, i])) for i in range(k)]
 
 
+def match_all_batch(exe, data, cap, do_leader=True, *, offsets=None, stride=0, n=None):
+    """matchAll (include/Matcher.h:711-766; the reference's public entry, lib/Matcher.cpp:97-102,
+    runs with doLeader = true) over every line: one anchored walk reporting each maximal run of
+    one accepted result.  Same return shape as collect_batch."""
+    a = _host_u8(data)
+    if offsets is not None:
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        stride = 0
+    elif n is None:
+        n = a.size // stride if stride else 0
+    counts = np.zeros(n, dtype=np.uint64)
+    res = np.zeros((n, cap), dtype=np.int32)
+    st = np.zeros((n, cap), dtype=np.uint64)
+    en = np.zeros((n, cap), dtype=np.uint64)
+    _check(_lib.lib().redgpu_match_all_batch(
+        exe._h, int(bool(do_leader)), a.ctypes.data if a.size else None,
+        offsets.ctypes.data if offsets is not None else None, stride, n, cap, counts.ctypes.data,
+        res.ctypes.data, st.ctypes.data, en.ctypes.data))
+    return counts, res, st, en
+
+
+def match_all(exe, text: bytes, cap: int = 64):
+    """matchAll(exec, text, out) on one text -> list of (result, start, end)."""
+    counts, res, st, en = match_all_batch(exe, text, cap, True, offsets=[0, len(text)])
+    k = int(min(counts[0], cap))
+    return [(int(res[0, i]), int(st[0, i]), int(en[0, i])) for i in range(k)]
+
+
+STATE_INITIAL = 0xFFFFFFFF
+
+
+def advance_batch(exe, data, state, *, offsets=None, stride=0, n=None, out=None):
+    """n StatefulMatchers (include/Matcher.h:770-792) advanced by one chunk each.
+    `state` (uint32[n], in/out, updated in place) holds each matcher's state token -
+    STATE_INITIAL for a fresh matcher; returns result int32[n] = result() after the chunk.
+    numpy arrays run through the host entry point, torch CUDA tensors (data uint8, state int32
+    viewed as u32) asynchronously on the current stream."""
+    l = _lib.lib()
+    if _is_torch(data):
+        import torch
+        if not data.is_cuda or data.dtype != torch.uint8 or not data.is_contiguous():
+            raise RedExceptApi("device input must be a contiguous uint8 CUDA tensor")
+        dev = data.device
+        if offsets is not None:
+            if (not _is_torch(offsets) or offsets.dtype not in (torch.int64, torch.uint64)
+                    or not offsets.is_cuda or not offsets.is_contiguous()):
+                raise RedExceptApi("device offsets must be a contiguous int64 CUDA tensor")
+            n = offsets.numel() - 1
+            stride = 0
+        elif n is None:
+            n = data.numel() // stride if stride else 0
+        if (not _is_torch(state) or state.numel() != n or state.element_size() != 4 or
+                state.device != dev or not state.is_contiguous()):
+            raise RedExceptApi("state must be a 4-byte tensor of n elements on the data's device")
+        res = out if out is not None else torch.empty(n, dtype=torch.int32, device=dev)
+        _check(l.redgpu_advance_batch_dev(
+            exe._h, data.data_ptr(), offsets.data_ptr() if offsets is not None else None, stride,
+            n, state.data_ptr(), res.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+        return res
+    a = _host_u8(data)
+    if offsets is not None:
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        stride = 0
+    elif n is None:
+        n = a.size // stride if stride else 0
+    if not (isinstance(state, np.ndarray) and state.dtype == np.uint32 and state.size == n and
+            state.flags.c_contiguous):
+        raise RedExceptApi("state must be a contiguous uint32 array of n elements")
+    res = np.zeros(n, dtype=np.int32)
+    _check(l.redgpu_advance_batch(exe._h, a.ctypes.data if a.size else None,
+                                  offsets.ctypes.data if offsets is not None else None, stride,
+                                  n, state.ctypes.data, res.ctypes.data))
+    return res
+
+
+class StatefulMatcher:
+    """Mirror of zezax::red::StatefulMatcher (include/Matcher.h:770-792): `advance(byte)` and
+    `result()`; `advance_bytes` feeds a whole chunk in one kernel launch.  The executable must
+    outlive the matcher, as in the reference."""
+
+    def __init__(self, exe):
+        self._exe = exe
+        self._state = np.full(1, STATE_INITIAL, dtype=np.uint32)
+        self._result = int(advance_batch(exe, b"", self._state, offsets=[0, 0])[0])
+
+    def advance(self, byte) -> int:
+        b = bytes([byte]) if isinstance(byte, int) else bytes(byte[:1])
+        return self.advance_bytes(b)
+
+    def advance_bytes(self, chunk: bytes) -> int:
+        self._result = int(advance_batch(self._exe, chunk, self._state,
+                                         offsets=[0, len(chunk)])[0])
+        return self._result
+
+    def result(self) -> int:
+        return self._result
+
+
 # single-input forms keep the reference's signatures; they are batches of one ON THE GPU
 def check(exe, text: bytes, style, do_leader=True) -> int:
     return int(check_batch(exe, text, style, do_leader, offsets=[0, len(text)])[0])

@@ -86,6 +86,19 @@ def _orc():
         lib.oracle_collect_batch.argtypes = [C.POINTER(_Dfa), C.c_void_p, C.c_void_p, C.c_uint64,
                                              C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.oracle_match_all.restype = C.c_uint64
+        lib.oracle_match_all.argtypes = [C.POINTER(_Dfa), C.c_void_p, C.c_size_t, C.c_int,
+                                         C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.oracle_match_all_batch.restype = None
+        lib.oracle_match_all_batch.argtypes = [C.POINTER(_Dfa), C.c_int, C.c_void_p, C.c_void_p,
+                                               C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.oracle_advance.restype = C.c_int32
+        lib.oracle_advance.argtypes = [C.POINTER(_Dfa), C.POINTER(C.c_uint32), C.c_void_p,
+                                       C.c_size_t, C.c_void_p]
+        lib.oracle_advance_batch.restype = None
+        lib.oracle_advance_batch.argtypes = [C.POINTER(_Dfa), C.c_void_p, C.c_void_p, C.c_uint64,
+                                             C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
         lib.oracle_batch.restype = None
         lib.oracle_batch.argtypes = [C.POINTER(_Dfa), C.c_int, C.c_int, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
@@ -224,6 +237,65 @@ class CpuOracle(_Batchable):
         return counts, res, st, en
 
 
+    def match_all(self, text: bytes, do_leader=True, cap: int = 64):
+        """matchAll (Matcher.h:711-766): list of (result, start, end), and the number found."""
+        res = np.zeros(cap, dtype=np.int32)
+        st = np.zeros(cap, dtype=np.uint64)
+        en = np.zeros(cap, dtype=np.uint64)
+        k = _orc().oracle_match_all(C.byref(self._d), text, len(text), int(bool(do_leader)), cap,
+                                    res.ctypes.data, st.ctypes.data, en.ctypes.data)
+        m = min(k, cap)
+        return [(int(res[i]), int(st[i]), int(en[i])) for i in range(m)], int(k)
+
+    def match_all_batch(self, data, cap, *, do_leader=True, offsets=None, stride=0, n=None):
+        """-> counts uint64[n], result int32[n,cap], start uint64[n,cap], end uint64[n,cap]"""
+        data = _as_u8(data)
+        if offsets is not None:
+            offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+            n = len(offsets) - 1
+        elif n is None:
+            n = len(data) // stride if stride else 0
+        counts = np.zeros(n, dtype=np.uint64)
+        res = np.zeros((n, cap), dtype=np.int32)
+        st = np.zeros((n, cap), dtype=np.uint64)
+        en = np.zeros((n, cap), dtype=np.uint64)
+        if n:
+            _orc().oracle_match_all_batch(C.byref(self._d), int(bool(do_leader)), data.ctypes.data,
+                                          offsets.ctypes.data if offsets is not None else None,
+                                          int(stride), int(stride), n, cap, counts.ctypes.data,
+                                          res.ctypes.data, st.ctypes.data, en.ctypes.data)
+        return counts, res, st, en
+
+    def stateful(self, text: bytes):
+        """A fresh StatefulMatcher advanced over text -> (result(), int32[len] of every
+        advance()'s return value)."""
+        per = np.zeros(max(1, len(text)), dtype=np.int32)
+        state = C.c_uint32(STATE_INITIAL)
+        r = _orc().oracle_advance(C.byref(self._d), C.byref(state), text, len(text),
+                                  per.ctypes.data)
+        return int(r), per[:len(text)]
+
+    def advance_batch(self, data, state, *, offsets=None, stride=0, n=None):
+        """state: uint32[n] in/out (oracle tokens: row byte offsets; STATE_INITIAL = fresh).
+        -> result int32[n]"""
+        data = _as_u8(data)
+        if offsets is not None:
+            offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+            n = len(offsets) - 1
+        elif n is None:
+            n = len(data) // stride if stride else 0
+        assert state.dtype == np.uint32 and len(state) == n and state.flags.c_contiguous
+        res = np.zeros(n, dtype=np.int32)
+        if n:
+            _orc().oracle_advance_batch(C.byref(self._d), data.ctypes.data,
+                                        offsets.ctypes.data if offsets is not None else None,
+                                        int(stride), int(stride), n, state.ctypes.data,
+                                        res.ctypes.data)
+        return res
+
+
+STATE_INITIAL = 0xFFFFFFFF
+
 # ------------------------------------------------------------------------------------------
 _libref = None
 
@@ -261,6 +333,11 @@ def _ref():
         lib.ref_collect.restype = C.c_uint64
         lib.ref_collect.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint64,
                                     C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ref_match_all.restype = C.c_uint64
+        lib.ref_match_all.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]
+        lib.ref_stateful.restype = C.c_int32
+        lib.ref_stateful.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, _i32p, C.c_void_p]
         lib.ref_batch.restype = None
         lib.ref_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p,
@@ -365,6 +442,24 @@ class Reference(_Batchable):
 
     def search(self, text: bytes, style, do_leader):
         return self._oc(_ref().ref_search, text, style, do_leader)
+
+    def match_all(self, text: bytes, cap: int = 64):
+        """The reference's matchAll(exec, sv, out) (always doLeader = true)."""
+        res = np.zeros(cap, dtype=np.int32)
+        st = np.zeros(cap, dtype=np.uint64)
+        en = np.zeros(cap, dtype=np.uint64)
+        k = _ref().ref_match_all(self._h, text, len(text), cap, res.ctypes.data, st.ctypes.data,
+                                 en.ctypes.data)
+        m = min(k, cap)
+        return [(int(res[i]), int(st[i]), int(en[i])) for i in range(m)], int(k)
+
+    def stateful(self, text: bytes):
+        """A fresh reference StatefulMatcher advanced over text ->
+        (result() before, result() after, int32[len] of every advance())."""
+        per = np.zeros(max(1, len(text)), dtype=np.int32)
+        ini = C.c_int32(0)
+        r = _ref().ref_stateful(self._h, text, len(text), C.byref(ini), per.ctypes.data)
+        return int(ini.value), int(r), per[:len(text)]
 
     def _batch_call(self, verb, style, lead, data, offsets, stride, line_len, n, res, st, en,
                     threads):

@@ -431,12 +431,115 @@ def gen_collect():
     print("collect: kat + %d inputs x 3 dfas" % len(ins))
 
 
+SET5 = [("0", 1, 0), ("0123", 2, 0), ("[0-2]+", 3, 0), ("[3-9]+", 4, 0), ("012345", 5, 0)]
+
+
+def gen_matchall_stateful():
+    """matchAll (include/Matcher.h:711-766) and StatefulMatcher (include/Matcher.h:770-792):
+    the known answers of test/matcher.cpp:695-745,800-818 and test/red.cpp:176-187, run through
+    the real reference in all four formats, + reference outputs on the mixed input set."""
+    kats = []
+    exp5 = [(1, 0, 1), (3, 0, 3), (2, 0, 4), (5, 0, 6)]
+    expl = [(1, None, 3), (2, None, 6), (2, None, 9), (1, None, 12), (2, None, 14), (1, None, 15)]
+    for fmt, blob in compile_all_formats(SET5).items():
+        if isinstance(blob, tuple):
+            continue
+        got, k = O.Reference(blob).match_all(b"0123456789")
+        assert k == 4 and got == exp5, got
+        kats.append(dict(src="test/matcher.cpp:695-723 (and test/red.cpp:176-187)", fmt=fmt,
+                         reda=b64(blob), text=b64(b"0123456789"), count=4,
+                         expect=[list(x) for x in got]))
+    for fmt, blob in compile_all_formats([("a+", 1, LS), ("b+", 2, LS)]).items():
+        if isinstance(blob, tuple):
+            continue
+        got, k = O.Reference(blob).match_all(b".aa..b.bb..abba.")
+        assert k == 6 and all(g[0] == e[0] and g[2] == e[2] for g, e in zip(got, expl)), got
+        kats.append(dict(src="test/matcher.cpp:725-745 (start_ not asserted there; the "
+                             "reference's own output is recorded)", fmt=fmt, reda=b64(blob),
+                         text=b64(b".aa..b.bb..abba."), count=6, expect=[list(x) for x in got]))
+    skat = []
+    for fmt, blob in compile_all_formats([("ale+", 1, 0), ("ale*x", 2, 0)]).items():
+        if isinstance(blob, tuple):
+            continue
+        ini, fin, per = O.Reference(blob).stateful(b"aleex")
+        assert ini == 0 and fin == 2 and per.tolist() == [0, 0, 1, 1, 2]
+        skat.append(dict(src="test/matcher.cpp:800-818", fmt=fmt, reda=b64(blob),
+                         text=b64(b"aleex"), initial=0, per_byte=per.tolist(), final=2))
+    # blobs for the C++ mirror test (tests/cpp/matcher_cabi_test.cpp)
+    for name, pats in (("set5", SET5), ("loose2", [("a+", 1, LS), ("b+", 2, LS)]),
+                       ("ale", [("ale+", 1, 0), ("ale*x", 2, 0)]),
+                       ("newyork4", [("new york", 1, 0), ("new", 2, 0), ("york", 3, 0),
+                                     ("[0-9]+", 4, 0)])):
+        with open(os.path.join(GOLD, "dfas", name + ".reda"), "wb") as f:
+            f.write(O.ref_compile(pats))
+    with open(os.path.join(GOLD, "matchall_kat.json"), "w") as f:
+        json.dump(kats, f)
+    with open(os.path.join(GOLD, "stateful_kat.json"), "w") as f:
+        json.dump(skat, f)
+
+    rng = np.random.default_rng(0xA11)
+    ins = inputs_for("matchall", rng)[:1100]
+    ins += [b"0123456789", b".aa..b.bb..abba.", b"aleex", b"", b"0", b"00123", b"9876543210" * 30]
+    data = np.frombuffer(b"".join(ins), dtype=np.uint8)
+    offsets = np.zeros(len(ins) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(x) for x in ins])
+    cap = 8  # small on purpose: some inputs overflow it, counts keep counting
+    dfas = config_dfas()
+    sets = dict(set5=O.ref_compile(SET5), loose2=O.ref_compile([("a+", 1, LS), ("b+", 2, LS)]),
+                num3=dfas["num3"], newyork=dfas["newyork"], err=dfas["err"], uri=dfas["uri"],
+                log100=dfas["log100"], syn256=dfas["syn256"])
+    arrays = dict(data=data, offsets=offsets, cap=np.array([cap]))
+    for name, b in sets.items():
+        ref, cpu = O.Reference(b), O.CpuOracle(b)
+        counts = np.zeros(len(ins), dtype=np.uint64)
+        res = np.zeros((len(ins), cap), dtype=np.int32)
+        st = np.zeros((len(ins), cap), dtype=np.uint64)
+        en = np.zeros((len(ins), cap), dtype=np.uint64)
+        for i, t in enumerate(ins):
+            got, k = ref.match_all(t, cap)
+            assert (got, k) == cpu.match_all(t, True, cap), (name, t)
+            counts[i] = k
+            for j, (r, s_, e_) in enumerate(got):
+                res[i, j], st[i, j], en[i, j] = r, s_, e_
+        c2, r2, s2, e2 = cpu.match_all_batch(data, cap, do_leader=True, offsets=offsets)
+        assert (c2 == counts).all() and (r2 == res).all() and (s2 == st).all() and (e2 == en).all()
+        arrays[name + "_blob"] = np.frombuffer(b, dtype=np.uint8)
+        arrays[name + "_lead1_counts"], arrays[name + "_lead1_res"] = counts, res
+        arrays[name + "_lead1_start"], arrays[name + "_lead1_end"] = st, en
+        # doLeader = false has no public entry in the reference (lib/Matcher.cpp:101 fixes it
+        # to true); where the DFA has no leader the two are the same walk, which is asserted,
+        # and for the DFAs with one the restatement's output is recorded.
+        c0, r0, s0, e0 = cpu.match_all_batch(data, cap, do_leader=False, offsets=offsets)
+        if cpu.info["leaderLen"] == 0:
+            assert (c0 == counts).all() and (r0 == res).all() and (e0 == en).all()
+        arrays[name + "_lead0_counts"], arrays[name + "_lead0_res"] = c0, r0
+        arrays[name + "_lead0_start"], arrays[name + "_lead0_end"] = s0, e0
+        # StatefulMatcher: every advance() of a fresh matcher over every input
+        per = np.zeros(len(data), dtype=np.int32)
+        fin = np.zeros(len(ins), dtype=np.int32)
+        ini = np.zeros(1, dtype=np.int32)
+        for i, t in enumerate(ins):
+            a, z, pb = ref.stateful(t)
+            z2, pb2 = cpu.stateful(t)
+            assert z == z2 and (pb == pb2).all(), (name, t)
+            ini[0] = a
+            fin[i] = z
+            per[int(offsets[i]):int(offsets[i + 1])] = pb
+        arrays[name + "_sm_initial"], arrays[name + "_sm_final"] = ini, fin
+        arrays[name + "_sm_per_byte"] = per
+    np.savez_compressed(os.path.join(GOLD, "matchall_stateful_vectors.npz"), **arrays)
+    print("matchAll/stateful: %d + %d kats, %d inputs x %d dfas" %
+          (len(kats), len(skat), len(ins), len(sets)))
+
+
 def main():
     os.makedirs(os.path.join(GOLD, "dfas"), exist_ok=True)
-    gen_kat()
-    gen_omnibus()
-    gen_vectors()
-    gen_collect()
+    only = sys.argv[1:]
+    steps = dict(kat=gen_kat, omnibus=gen_omnibus, vectors=gen_vectors, collect=gen_collect,
+                 matchall=gen_matchall_stateful)
+    for name, fn in steps.items():
+        if not only or name in only:
+            fn()
 
 
 if __name__ == "__main__":

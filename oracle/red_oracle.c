@@ -457,6 +457,118 @@ void oracle_collect_batch(const oracle_dfa *d, const uint8_t *data, const uint64
   }
 }
 
+/* ---- include/Matcher.h:711-766 matchAllCore (public entry matchAll, lib/Matcher.cpp:97-102,
+ * always <styTangent, doLeader=true>; the style parameter is unused by the core) ---------- */
+ORA_INLINE uint64_t match_all_core(const oracle_dfa *d, const uint8_t *p, size_t n,
+                                   const int lead, const int V, uint64_t cap, int32_t *res,
+                                   uint64_t *start, uint64_t *end) {
+  const uint8_t *stop = p + n;
+  const uint8_t *base = d->base;
+  const uint8_t *equiv = d->equiv;
+  uint64_t found = 0; /* out.size() */
+
+  if (lead && !looking_at(p, stop, d))
+    return 0;
+
+  const uint8_t *init = base + d->initialOff;
+  const uint8_t *st = init;
+  int32_t prevResult = 0;
+  size_t idx = 0;
+  size_t matchStart = 0;
+
+  for (; p < stop; ++p, ++idx) {
+    unsigned cls = equiv[*p];
+    if (ORA_UNLIKELY(st == init)) {
+      const uint8_t *prevState = st;
+      st = st_next(base, st, cls, V);
+      if (st != prevState)
+        matchStart = idx;
+    } else
+      st = st_next(base, st, cls, V);
+    int32_t result = st_result(st, V);
+    if (ORA_UNLIKELY(result > 0)) {
+      if (result == prevResult) {
+        if (found - 1 < cap)
+          end[found - 1] = idx + 1; /* out.back().end_ */
+      } else {
+        prevResult = result;
+        if (found < cap) {
+          res[found] = result;
+          start[found] = matchStart;
+          end[found] = idx + 1;
+        }
+        ++found;
+      }
+    } else {
+      if (st_pure_dead(st, V))
+        break;
+      prevResult = 0;
+    }
+  }
+  return found;
+}
+
+uint64_t oracle_match_all(const oracle_dfa *d, const uint8_t *p, size_t n, int doLeader,
+                          uint64_t cap, int32_t *res, uint64_t *start, uint64_t *end) {
+  const int lead = doLeader ? 1 : 0;
+  switch (d->fmt) {
+  case 1: return match_all_core(d, p, n, lead, 1, cap, res, start, end);
+  case 2: return match_all_core(d, p, n, lead, 2, cap, res, start, end);
+  case 4: return match_all_core(d, p, n, lead, 4, cap, res, start, end);
+  default: return 0;
+  }
+}
+
+void oracle_match_all_batch(const oracle_dfa *d, int doLeader, const uint8_t *data,
+                            const uint64_t *offsets, uint64_t stride, uint64_t lineLen,
+                            uint64_t n, uint64_t cap, uint64_t *counts, int32_t *res,
+                            uint64_t *start, uint64_t *end) {
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint8_t *p = offsets ? data + offsets[i] : data + i * stride;
+    size_t len = offsets ? (size_t)(offsets[i + 1] - offsets[i]) : (size_t)lineLen;
+    counts[i] = oracle_match_all(d, p, len, doLeader, cap, res + i * cap, start + i * cap,
+                                 end + i * cap);
+  }
+}
+
+/* ---- include/Matcher.h:770-792, lib/Matcher.cpp:106-158 StatefulMatcher ----------------
+ * *state is the matcher's state_ as a byte offset from base; ORA_STATE_INITIAL stands for a
+ * freshly constructed matcher (state_ = the initial row, lib/Matcher.cpp:113-136).  Advances
+ * over p[0..n) one advance() per byte; returns result() after the last one.  perByte (may be
+ * NULL) receives the return value of every advance(). */
+ORA_INLINE int32_t advance_core(const oracle_dfa *d, uint32_t *state, const uint8_t *p, size_t n,
+                                const int V, int32_t *perByte) {
+  const uint8_t *base = d->base;
+  const uint8_t *st = base + (*state == ORA_STATE_INITIAL ? d->initialOff : *state);
+  for (size_t i = 0; i < n; ++i) {
+    st = st_next(base, st, d->equiv[p[i]], V);
+    if (perByte)
+      perByte[i] = st_result(st, V);
+  }
+  *state = (uint32_t)(st - base);
+  return st_result(st, V);
+}
+
+int32_t oracle_advance(const oracle_dfa *d, uint32_t *state, const uint8_t *p, size_t n,
+                       int32_t *perByte) {
+  switch (d->fmt) {
+  case 1: return advance_core(d, state, p, n, 1, perByte);
+  case 2: return advance_core(d, state, p, n, 2, perByte);
+  case 4: return advance_core(d, state, p, n, 4, perByte);
+  default: return ORA_BAD;
+  }
+}
+
+void oracle_advance_batch(const oracle_dfa *d, const uint8_t *data, const uint64_t *offsets,
+                          uint64_t stride, uint64_t lineLen, uint64_t n, uint32_t *state,
+                          int32_t *res) {
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint8_t *p = offsets ? data + offsets[i] : data + i * stride;
+    size_t len = offsets ? (size_t)(offsets[i + 1] - offsets[i]) : (size_t)lineLen;
+    res[i] = oracle_advance(d, &state[i], p, len, NULL);
+  }
+}
+
 /* ---- batch: the callers' outer loop, N threads over contiguous shards
  * (tools/thr_red.cpp:36-47,86-91; tools/bench.cpp:60-71) -------------------------------- */
 typedef struct {

@@ -78,6 +78,25 @@ void oracle_collect_batch(const oracle_dfa *d, const uint8_t *data, const uint64
                           uint64_t stride, uint64_t lineLen, uint64_t n, uint64_t cap,
                           uint64_t *counts, int32_t *res, uint64_t *start, uint64_t *end);
 
+/* include/Matcher.h:711-766 matchAllCore; the public matchAll (lib/Matcher.cpp:97-102) runs it
+ * with doLeader = 1.  Same cap / count convention as oracle_collect. */
+uint64_t oracle_match_all(const oracle_dfa *d, const uint8_t *p, size_t n, int doLeader,
+                          uint64_t cap, int32_t *res, uint64_t *start, uint64_t *end);
+void oracle_match_all_batch(const oracle_dfa *d, int doLeader, const uint8_t *data,
+                            const uint64_t *offsets, uint64_t stride, uint64_t lineLen,
+                            uint64_t n, uint64_t cap, uint64_t *counts, int32_t *res,
+                            uint64_t *start, uint64_t *end);
+
+/* include/Matcher.h:770-792, lib/Matcher.cpp:106-158 StatefulMatcher: *state = state_ as a byte
+ * offset from base (ORA_STATE_INITIAL = freshly constructed); one advance() per byte of p;
+ * returns result(); perByte (may be NULL) gets every advance()'s return value. */
+#define ORA_STATE_INITIAL 0xffffffffu
+int32_t oracle_advance(const oracle_dfa *d, uint32_t *state, const uint8_t *p, size_t n,
+                       int32_t *perByte);
+void oracle_advance_batch(const oracle_dfa *d, const uint8_t *data, const uint64_t *offsets,
+                          uint64_t stride, uint64_t lineLen, uint64_t n, uint32_t *state,
+                          int32_t *res);
+
 /* The callers' per-input loop (tools/bench.cpp:60-71, tools/thr_red.cpp:36-47,86-91):
  * line i = data[offsets[i], offsets[i+1]) or, with offsets == NULL,
  * data[i*stride, i*stride + lineLen).  start/end may be NULL.  nthreads contiguous shards. */

@@ -242,6 +242,34 @@ uint64_t ref_collect(const void *blob, size_t len, const void *text, size_t n, u
   return out.size();
 }
 
+/* matchAll(exec, string_view, vector<Outcome>&) (include/Matcher.h:127, lib/Matcher.cpp:97-102) */
+uint64_t ref_match_all(void *ex, const void *text, size_t n, uint64_t cap, int32_t *res,
+                       uint64_t *start, uint64_t *end) {
+  std::vector<Outcome> out;
+  matchAll(*static_cast<Executable *>(ex),
+           std::string_view(static_cast<const char *>(text), n), out);
+  for (size_t i = 0; i < out.size() && i < cap; ++i) {
+    res[i] = out[i].result_;
+    start[i] = out[i].start_;
+    end[i] = out[i].end_;
+  }
+  return out.size();
+}
+
+/* StatefulMatcher (include/Matcher.h:770-792): a fresh matcher advanced over text byte by
+ * byte; perByte[i] = advance(text[i]); *initial = result() before the first byte; returns
+ * result() after the last. */
+int32_t ref_stateful(void *ex, const void *text, size_t n, int32_t *initial, int32_t *perByte) {
+  StatefulMatcher sm(*static_cast<Executable *>(ex));
+  if (initial) *initial = sm.result();
+  const Byte *p = static_cast<const Byte *>(text);
+  for (size_t i = 0; i < n; ++i) {
+    Result r = sm.advance(p[i]);
+    if (perByte) perByte[i] = r;
+  }
+  return sm.result();
+}
+
 /* Batch forms: the outer per-input loop of tools/bench.cpp:60-71 / thr_red.cpp:36-47,
  * with N std::threads over contiguous shards exactly as thr_red.cpp:86-91 does.
  * verb: 0 check, 1 match, 2 scan, 3 search.  start/end may be NULL. */

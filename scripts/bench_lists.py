@@ -1,0 +1,49 @@
+"""GB/s of the "next row" verbs: StatefulMatcher chunks (advance), matchAll,
+collect, search - one stream, inputs resident.  Developer tool (bench.py is the contract bench).
+usage: bench_lists.py [dfa-name]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C
+import torch, one_amd
+from one_amd import _lib
+name = sys.argv[1] if len(sys.argv) > 1 else "syn256"
+blob = open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "dfas", name + ".reda"), "rb").read()
+exe = one_amd.Executable(blob)
+l = _lib.lib()
+
+
+def timed(fn, it):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(it):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / it
+
+
+for n, L in [(1 << 20, 64), (1 << 18, 4096), (1 << 20, 96)]:
+    total = n * L
+    data = torch.randint(0, 256, (total,), dtype=torch.uint8, device="cuda")
+    state = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    res = torch.empty(n, dtype=torch.int32, device="cuda")
+    ms = timed(lambda: one_amd.advance_batch(exe, data, state, stride=L, n=n, out=res), 50)
+    print("advance   %8d x %5d B  %8.1f us  %7.1f GB/s  %s" % (n, L, ms * 1e3, total / ms / 1e6, one_amd.last_kernel()), flush=True)
+    cap = 4
+    cnt = torch.empty(n, dtype=torch.int64, device="cuda")
+    r = torch.empty(n * cap, dtype=torch.int32, device="cuda")
+    s = torch.empty(n * cap, dtype=torch.int64, device="cuda")
+    e = torch.empty(n * cap, dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for label, fn in (
+            ("matchAll", lambda: l.redgpu_match_all_batch_dev(exe._h, 1, data.data_ptr(), None, L, n, cap, cnt.data_ptr(), r.data_ptr(), s.data_ptr(), e.data_ptr(), stream)),
+            ("collect", lambda: l.redgpu_collect_batch_dev(exe._h, data.data_ptr(), None, L, n, cap, cnt.data_ptr(), r.data_ptr(), s.data_ptr(), e.data_ptr(), stream))):
+        if label == "collect" and L > 1024:
+            continue
+        ms = timed(fn, 10)
+        print("%-9s %8d x %5d B  %8.1f us  %7.1f GB/s  %s" % (label, n, L, ms * 1e3, total / ms / 1e6, one_amd.last_kernel()), flush=True)
+    del data
+    torch.cuda.empty_cache()

@@ -58,6 +58,65 @@ int main(int argc, char **argv) {
     EXPECT_EQ(size_t(15), ocs[2].end_);
     EXPECT_EQ(0, ocs[3].result_);
   }
+  // test/matcher.cpp:695-723 matchAll
+  {
+    Executable rex(slurp(dir + "/set5.reda"));
+    std::vector<Outcome> vec;
+    EXPECT_EQ(size_t(4), matchAll(rex, "0123456789", vec));
+    EXPECT_EQ(size_t(4), vec.size());
+    EXPECT_EQ(1, vec[0].result_);
+    EXPECT_EQ(size_t(0), vec[0].start_);
+    EXPECT_EQ(size_t(1), vec[0].end_);
+    EXPECT_EQ(3, vec[1].result_);
+    EXPECT_EQ(size_t(3), vec[1].end_);
+    EXPECT_EQ(2, vec[2].result_);
+    EXPECT_EQ(size_t(4), vec[2].end_);
+    EXPECT_EQ(5, vec[3].result_);
+    EXPECT_EQ(size_t(0), vec[3].start_);
+    EXPECT_EQ(size_t(6), vec[3].end_);
+  }
+  // test/matcher.cpp:725-745 matchAllLoose
+  {
+    Executable rex(slurp(dir + "/loose2.reda"));
+    std::vector<Outcome> vec;
+    EXPECT_EQ(size_t(6), matchAll(rex, ".aa..b.bb..abba.", vec));
+    const int expR[6] = {1, 2, 2, 1, 2, 1};
+    const size_t expE[6] = {3, 6, 9, 12, 14, 15};
+    for (int i = 0; i < 6 && i < int(vec.size()); ++i) {
+      EXPECT_EQ(expR[i], vec[i].result_);
+      EXPECT_EQ(expE[i], vec[i].end_);
+    }
+    // more records than the first pass has room for
+    std::string many;
+    for (int i = 0; i < 40; ++i) many += "ab";
+    EXPECT_EQ(size_t(80), matchAll(rex, many, vec));
+    EXPECT_EQ(size_t(80), vec.back().end_);
+  }
+  // test/matcher.cpp:800-818 charByChar
+  {
+    Executable rex(slurp(dir + "/ale.reda"));
+    StatefulMatcher sm(rex);
+    EXPECT_EQ(0, sm.result());
+    EXPECT_EQ(0, sm.advance('a'));
+    EXPECT_EQ(0, sm.advance('l'));
+    EXPECT_EQ(1, sm.advance('e'));
+    EXPECT_EQ(1, sm.advance('e'));
+    EXPECT_EQ(2, sm.advance('x'));
+    EXPECT_EQ(2, sm.result());
+  }
+  // test/red.cpp:190-221 collect
+  {
+    Executable rex(slurp(dir + "/newyork4.reda"));
+    std::vector<Outcome> out;
+    EXPECT_EQ(size_t(5), collect(rex, "in new york12345, a new 6789 york city", out));
+    const int expR[5] = {1, 4, 2, 4, 3};
+    const size_t expS[5] = {3, 11, 20, 24, 29}, expE[5] = {11, 16, 23, 28, 33};
+    for (int i = 0; i < 5 && i < int(out.size()); ++i) {
+      EXPECT_EQ(expR[i], out[i].result_);
+      EXPECT_EQ(expS[i], out[i].start_);
+      EXPECT_EQ(expE[i], out[i].end_);
+    }
+  }
   // errors: test/red.cpp:128-130 (non-REDA -> RedExceptApi), lib/Matcher.cpp:45 (bad style)
   {
     bool threw = false;

@@ -372,3 +372,119 @@ def test_ragged_stream_kernel_tail_and_shapes(name):
                                   cpu.batch("check", si, 0, data, offsets=offsets)[0])
     one_amd.match_batch(exe, data, 4, 0, offsets=offsets)
     assert one_amd.last_kernel().startswith("k_ragged")
+
+
+def test_match_all_on_gpu():
+    """matchAll batch form (include/Matcher.h:711-766) vs the reference's known answers
+    (test/matcher.cpp:695-745, every format) and the reference outputs in
+    tests/golden/matchall_stateful_vectors.npz, LDS and global table placements, both doLeader."""
+    import json
+    import os
+    from golden_util import GOLD
+    for k in json.load(open(os.path.join(GOLD, "matchall_kat.json"))):
+        exe = one_amd.Executable(unb64(k["reda"]))
+        assert one_amd.match_all(exe, unb64(k["text"])) == [tuple(x) for x in k["expect"]], k["src"]
+        assert one_amd.match_all(exe, b"") == []
+    vec = np.load(os.path.join(GOLD, "matchall_stateful_vectors.npz"))
+    cap = int(vec["cap"][0])
+    for name in ("set5", "loose2", "num3", "newyork", "err", "uri", "log100", "syn256"):
+        for kw in ({}, {"force_global": True}):
+            exe = one_amd.Executable(vec[name + "_blob"].tobytes(), **kw)
+            for lead in (1, 0):
+                counts, res, st, en = one_amd.match_all_batch(exe, vec["data"], cap, lead,
+                                                              offsets=vec["offsets"])
+                key = "%s_lead%d_" % (name, lead)
+                assert np.array_equal(counts, vec[key + "counts"]), key
+                # slots beyond min(count, cap) are unspecified: compare the filled prefix only
+                k = np.minimum(counts, cap).astype(np.int64)
+                mask = np.arange(cap)[None, :] < k[:, None]
+                assert np.array_equal(res[mask], vec[key + "res"][mask]), key
+                assert np.array_equal(st[mask], vec[key + "start"][mask]), key
+                assert np.array_equal(en[mask], vec[key + "end"][mask]), key
+    # fixed-stride form against the oracle
+    blob = load_dfa("syn256")
+    exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
+    data = W.fixed_lines(3000, 96, 11, alphabet=False)
+    got = one_amd.match_all_batch(exe, data, 4, True, stride=96, n=3000)
+    exp = cpu.match_all_batch(data, 4, do_leader=True, stride=96, n=3000)
+    assert np.array_equal(got[0], exp[0])
+    mask = np.arange(4)[None, :] < np.minimum(exp[0], 4).astype(np.int64)[:, None]
+    for g, e in zip(got[1:], exp[1:]):
+        assert np.array_equal(g[mask], e[mask])
+
+
+def test_stateful_matcher_on_gpu():
+    """StatefulMatcher (include/Matcher.h:770-792): the reference's charByChar known answer
+    (test/matcher.cpp:800-818) byte by byte, then n matchers advanced chunk by chunk - the state
+    carried across three launches - against every advance() of the reference recorded in
+    tests/golden/matchall_stateful_vectors.npz."""
+    import json
+    import os
+    from golden_util import GOLD
+    for k in json.load(open(os.path.join(GOLD, "stateful_kat.json"))):
+        exe = one_amd.Executable(unb64(k["reda"]))
+        sm = one_amd.StatefulMatcher(exe)
+        assert sm.result() == k["initial"]
+        got = [sm.advance(b) for b in unb64(k["text"])]
+        assert got == k["per_byte"] and sm.result() == k["final"]
+    vec = np.load(os.path.join(GOLD, "matchall_stateful_vectors.npz"))
+    data, offsets = vec["data"], vec["offsets"]
+    lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
+    rng = np.random.default_rng(3)
+    c1 = (rng.random(len(lens)) * (lens + 1)).astype(np.int64)          # 0..len
+    c2 = c1 + (rng.random(len(lens)) * (lens - c1 + 1)).astype(np.int64)  # c1..len
+    cuts = [np.zeros_like(lens), c1, c2, lens]
+    for name in ("set5", "loose2", "err", "uri", "log100", "syn256"):
+        per = vec[name + "_sm_per_byte"]
+        ini = int(vec[name + "_sm_initial"][0])
+        for kw in ({}, {"force_global": True}):
+            exe = one_amd.Executable(vec[name + "_blob"].tobytes(), **kw)
+            state = np.full(len(lens), one_amd.STATE_INITIAL, dtype=np.uint32)
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                # chunk i = bytes [a_i, b_i) of input i, packed back to back
+                clen = b - a
+                coff = np.zeros(len(lens) + 1, dtype=np.uint64)
+                coff[1:] = np.cumsum(clen)
+                idx = np.concatenate([np.arange(int(offsets[i]) + int(a[i]),
+                                                int(offsets[i]) + int(b[i]))
+                                      for i in range(len(lens))]) if clen.sum() else \
+                    np.zeros(0, dtype=np.int64)
+                chunk = data[idx]
+                res = one_amd.advance_batch(exe, chunk, state, offsets=coff)
+                # result() after byte b_i - 1 of input i (or the initial result when b_i == 0)
+                pos = offsets[:-1].astype(np.int64) + b - 1
+                exp = np.where(b > 0, per[np.maximum(pos, 0)], ini)
+                assert np.array_equal(res, exp), (name, kw)
+            assert np.array_equal(res, vec[name + "_sm_final"])
+    # fixed-stride chunks on the device, state resident between launches (torch plumbing)
+    import torch
+    blob = load_dfa("syn256")
+    exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
+    n, L = 5000, 192
+    host = W.fixed_lines(n, L, 21, alphabet=False)
+    dev = torch.from_numpy(host).cuda()
+    state = torch.full((n,), -1, dtype=torch.int32, device="cuda")   # 0xffffffff = fresh
+    for lo in range(0, L, 64):
+        chunk = dev.view(n, L)[:, lo:lo + 64].contiguous().view(-1)
+        res = one_amd.advance_batch(exe, chunk, state, stride=64, n=n)
+        assert one_amd.last_kernel() == "k_stream<advance>"
+    torch.cuda.synchronize()
+    exp = cpu.batch("check", "full", 0, host, stride=L, n=n)[0]
+    assert np.array_equal(res.cpu().numpy(), exp)
+    # the same walk through the generic kernel must leave the same state tokens behind
+    state_g = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    exe_g = one_amd.Executable(blob, force_generic=True)
+    res_g = one_amd.advance_batch(exe_g, dev, state_g, stride=L, n=n)
+    assert one_amd.last_kernel() == "k_advance"
+    assert torch.equal(res_g, res) and torch.equal(state_g, state)
+    # 128-byte blocks (HALVES = 2) and a ragged last tile
+    state2 = torch.full((n - 3,), -1, dtype=torch.int32, device="cuda")
+    res2 = one_amd.advance_batch(exe, dev[:(n - 3) * L].view(-1), state2, stride=L, n=n - 3)
+    assert one_amd.last_kernel() == "k_stream<advance>"
+    # L = 192 is not a multiple of 128: HALVES = 1; 256-byte chunks of the first 128 lines' worth
+    assert torch.equal(res2, res[:n - 3]) and torch.equal(state2, state[:n - 3])
+    m = (n * L) // 256
+    state3 = torch.full((m,), -1, dtype=torch.int32, device="cuda")
+    res3 = one_amd.advance_batch(exe, dev[:m * 256], state3, stride=256, n=m)
+    exp3 = cpu.batch("check", "full", 0, host[:m * 256], stride=256, n=m)[0]
+    assert np.array_equal(res3.cpu().numpy(), exp3)

@@ -106,3 +106,53 @@ def test_collect_kat_and_vectors():
         assert np.array_equal(counts, vec[name + "_counts"])
         assert np.array_equal(res, vec[name + "_res"])
         assert np.array_equal(st, vec[name + "_start"]) and np.array_equal(en, vec[name + "_end"])
+
+
+def test_match_all_and_stateful_kat_and_vectors():
+    """matchAll (include/Matcher.h:711-766) and StatefulMatcher (include/Matcher.h:770-792):
+    the known answers of test/matcher.cpp:695-745,800-818 in every format, and the reference's
+    outputs on the mixed input set (cap 8 is overflowed by some inputs on purpose)."""
+    import json
+    import os
+    from golden_util import GOLD
+    for k in json.load(open(os.path.join(GOLD, "matchall_kat.json"))):
+        got, cnt = O.CpuOracle(unb64(k["reda"])).match_all(unb64(k["text"]))
+        assert cnt == k["count"] and got == [tuple(x) for x in k["expect"]], k["src"]
+    for k in json.load(open(os.path.join(GOLD, "stateful_kat.json"))):
+        cpu = O.CpuOracle(unb64(k["reda"]))
+        assert cpu.stateful(b"")[0] == k["initial"]
+        fin, per = cpu.stateful(unb64(k["text"]))
+        assert fin == k["final"] and per.tolist() == k["per_byte"]
+    vec = np.load(os.path.join(GOLD, "matchall_stateful_vectors.npz"))
+    cap = int(vec["cap"][0])
+    data, offsets = vec["data"], vec["offsets"]
+    for name in ("set5", "loose2", "num3", "newyork", "err", "uri", "log100", "syn256"):
+        cpu = O.CpuOracle(vec[name + "_blob"].tobytes())
+        for lead in (1, 0):
+            c, r, s, e = cpu.match_all_batch(data, cap, do_leader=lead, offsets=offsets)
+            key = "%s_lead%d_" % (name, lead)
+            assert np.array_equal(c, vec[key + "counts"]) and np.array_equal(r, vec[key + "res"])
+            assert np.array_equal(s, vec[key + "start"]) and np.array_equal(e, vec[key + "end"])
+        # stateful: whole inputs, then the same inputs cut in two chunks with the state carried
+        state = np.full(len(offsets) - 1, O.STATE_INITIAL, dtype=np.uint32)
+        assert np.array_equal(cpu.advance_batch(data, state, offsets=offsets),
+                              vec[name + "_sm_final"])
+        lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
+        cut = (lens // 3).astype(np.uint64)
+        mid = offsets[:-1] + cut
+        per = vec[name + "_sm_per_byte"]
+        state = np.full(len(lens), O.STATE_INITIAL, dtype=np.uint32)
+        offs_a = np.stack([offsets[:-1], mid], axis=1)
+        ra = np.array([cpu_adv(cpu, data, state, i, int(offs_a[i, 0]), int(offs_a[i, 1]))
+                       for i in range(len(lens))], dtype=np.int32)
+        exp_a = np.where(cut > 0, per[np.maximum(mid.astype(np.int64) - 1, 0)],
+                         vec[name + "_sm_initial"][0])
+        assert np.array_equal(ra, exp_a), name
+        rb = np.array([cpu_adv(cpu, data, state, i, int(mid[i]), int(offsets[i + 1]))
+                       for i in range(len(lens))], dtype=np.int32)
+        assert np.array_equal(rb, vec[name + "_sm_final"]), name
+
+
+def cpu_adv(cpu, data, state, i, lo, hi):
+    st = state[i:i + 1]
+    return int(cpu.advance_batch(data[lo:hi], st, offsets=np.array([0, hi - lo], dtype=np.uint64))[0])

@@ -23,6 +23,18 @@ def _compare(blob, data, offsets):
                     assert np.array_equal(x, y), (verb, sty, lead)
 
 
+def _compare_lists(blob, data, offsets, upto=150):
+    """matchAll (public entry: doLeader = true) and StatefulMatcher, input by input"""
+    ref, cpu = O.Reference(blob), O.CpuOracle(blob)
+    for i in range(min(upto, len(offsets) - 1)):
+        t = data[int(offsets[i]):int(offsets[i + 1])].tobytes()
+        assert ref.match_all(t, 8) == cpu.match_all(t, True, 8), t
+        ini, fin, per = ref.stateful(t)
+        fin2, per2 = cpu.stateful(t)
+        assert fin == fin2 and np.array_equal(per, per2), t
+        assert cpu.stateful(b"")[0] == ini
+
+
 def _ragged(rng, n, maxlen, hi):
     lens = rng.integers(0, maxlen, n)
     offsets = np.zeros(n + 1, dtype=np.uint64)
@@ -43,6 +55,7 @@ def test_random_regex_dfas(seed):
         data, offsets = _ragged(rng, 400, 24, 256)
         data = (data % 4 + ord("a")).astype(np.uint8)
         _compare(blob, data, offsets)
+    _compare_lists(blob, data, offsets)
 
 
 @pytest.mark.parametrize("seed", range(4))
@@ -56,3 +69,4 @@ def test_writer_blobs_accepted_by_reference(seed):
     rng = np.random.default_rng(seed + 100)
     data, offsets = _ragged(rng, 300, 80, 256)
     _compare(blob, data, offsets)
+    _compare_lists(blob, data, offsets)

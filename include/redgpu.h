@@ -61,6 +61,8 @@ typedef struct redgpu_opts {
 
 #define REDGPU_F_FORCE_GENERIC 1u /* never pick the specialised fixed-stride kernels */
 #define REDGPU_F_FORCE_GLOBAL  2u /* keep the transition table in HBM/L2 even if it fits LDS */
+#define REDGPU_F_FORCE_HOT     4u /* a table too big for LDS always gets hot rows in LDS, even
+                                     when the visit model finds no locality (tests, tuning) */
 
 /* table placements reported by redgpu_dfa_info */
 #define REDGPU_TAB_LDS_FUSED_U8   1 /* [state][byte] -> next state, u8,  in LDS */
@@ -68,6 +70,9 @@ typedef struct redgpu_opts {
 #define REDGPU_TAB_LDS_CLASS_U16  3 /* [state][class] u16 + equivalence map, both in LDS */
 #define REDGPU_TAB_GLOBAL_U16     4 /* [state][class] u16 in HBM/L2, equivalence map in LDS */
 #define REDGPU_TAB_GLOBAL_U32     5 /* [state][class] u32 in HBM/L2, equivalence map in LDS */
+#define REDGPU_TAB_HOT_U16        6 /* [state][class] u16 in HBM/L2 for every state, plus fused
+                                       [hot state][byte] u16 rows of the n_hot most-visited
+                                       states in LDS (device states [hot_lo, hot_lo + n_hot)) */
 
 typedef struct redgpu_info {
   uint32_t format;        /* 1, 2, 4: FileHeader.format_ (include/Serializer.h:34-40,47) */
@@ -83,6 +88,11 @@ typedef struct redgpu_info {
   int32_t  device;
   uint32_t checksum;      /* FileHeader.checksum_ */
   uint32_t fast_path;     /* 1 if the fixed-stride specialised kernels apply to this DFA */
+  uint32_t n_hot;         /* REDGPU_TAB_HOT_U16: rows resident in LDS (else 0) */
+  uint32_t hot_lo;        /* REDGPU_TAB_HOT_U16: first device state with an LDS row */
+  uint32_t hot_coverage_ppm; /* REDGPU_TAB_HOT_U16: share of the modelled visits (random-byte
+                             walk from the initial state) that land on LDS rows, per million */
+  uint32_t reserved;
 } redgpu_info;
 
 /* Replaces checkHeader (include/Serializer.h:109, lib/Serializer.cpp:270-298): returns

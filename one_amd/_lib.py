@@ -11,7 +11,7 @@ HEADER = os.path.join(os.path.dirname(HERE), "include", "redgpu.h")
 
 OK, EAPI, EEXEC, ELIMIT, EHIP = 0, -1, -2, -3, -5
 DEVICE_CURRENT, DEVICE_NONE = -1, -2
-F_FORCE_GENERIC, F_FORCE_GLOBAL = 1, 2
+F_FORCE_GENERIC, F_FORCE_GLOBAL, F_FORCE_HOT = 1, 2, 4
 
 
 class Opts(C.Structure):
@@ -25,7 +25,8 @@ class Info(C.Structure):
                 ("n_pure_dead", C.c_uint32), ("first_accept", C.c_uint32),
                 ("table_kind", C.c_uint32), ("table_bytes", C.c_uint64),
                 ("max_result", C.c_int32), ("device", C.c_int32), ("checksum", C.c_uint32),
-                ("fast_path", C.c_uint32)]
+                ("fast_path", C.c_uint32), ("n_hot", C.c_uint32), ("hot_lo", C.c_uint32),
+                ("hot_coverage_ppm", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 def build(force: bool = False) -> str:

@@ -64,7 +64,7 @@ const char *checkHeader(const void *ptr, size_t len) {
 }
 
 std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool forceGlobal,
-                       DfaImage &img, int &errCode) {
+                       DfaImage &img, int &errCode, bool forceHot) {
   errCode = REDGPU_EAPI;
   if (!reda || len == 0)
     return "serialized dfa is empty";
@@ -149,23 +149,118 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
       }
     }
   }
+  std::vector<uint32_t> bfsRank(stateCnt, 0xffffffffu);
+  for (uint32_t i = 0; i < reach.size(); ++i)
+    bfsRank[reach[i]] = i;
   std::sort(reach.begin(), reach.end());
 
-  // order: pure dead ends | other non-accepting | accepting   (stable in blob order)
   auto headOf = [&](uint32_t s) { return rdValue(rowOf(s), vsz); };
   auto klass = [&](uint32_t s) {
     const uint32_t hd = headOf(s);
     if (hd == deadBit) return 0;              // result 0 and dead-end flag: Proxy.h:139-141
     return (hd & resultMask) ? 2 : 1;
   };
+
+  // table placement (decided before the renumbering: the hot-row kind orders states its own way)
+  if (ldsTableMax == 0)
+    ldsTableMax = 144u * 1024u;
+  {
+    const uint64_t nR = reach.size();
+    const uint64_t fused8 = nR * 256u, fused16 = nR * 512u, class16 = nR * nCls * 2u;
+    if (!forceGlobal && nR <= 256 && fused8 <= ldsTableMax)
+      img.tableKind = REDGPU_TAB_LDS_FUSED_U8;
+    else if (!forceGlobal && nR <= 65536 && fused16 <= ldsTableMax)
+      img.tableKind = REDGPU_TAB_LDS_FUSED_U16;
+    else if (!forceGlobal && nR <= 65536 && class16 <= ldsTableMax)
+      img.tableKind = REDGPU_TAB_LDS_CLASS_U16;
+    else if (!forceGlobal && nR <= 65536 && ldsTableMax >= 8u * 512u)
+      img.tableKind = REDGPU_TAB_HOT_U16;
+    else if (nR <= 65536)
+      img.tableKind = REDGPU_TAB_GLOBAL_U16;
+    else
+      img.tableKind = REDGPU_TAB_GLOBAL_U32;
+  }
+
+  // Hot rows: which states deserve an LDS row?  Model: expected visits of a walk from the
+  // initial state over 64 bytes drawn half from all 256 values and half from printable ASCII
+  // (power iteration over the class table, class weights = bytes per class); ties - states the
+  // model never reaches, e.g. deep inside a signature - go by breadth-first distance from
+  // the initial state.  Pure dead ends are never looked up (the walk stops there).
+  std::vector<uint8_t> isHot(stateCnt, 0);
+  if (img.tableKind == REDGPU_TAB_HOT_U16) {
+    std::vector<double> w(nCls, 0.0);
+    for (uint32_t b = 0; b < 256; ++b) {
+      double wb = 0.5 / 256.0;
+      if ((b >= 0x20 && b <= 0x7e) || b == 0x09) wb += 0.5 / 96.0;
+      w[h[kOffEquivMap + b]] += wb;
+    }
+    std::vector<double> p(stateCnt, 0.0), q(stateCnt, 0.0), visits(stateCnt, 0.0);
+    p[rawInit] = 1.0;
+    for (int step = 0; step < 64; ++step) {
+      std::fill(q.begin(), q.end(), 0.0);
+      for (uint32_t s : reach) {
+        if (p[s] < 1e-15 || klass(s) == 0) continue;
+        for (uint32_t c = 0; c < nCls; ++c) {
+          uint32_t t = 0;
+          targetOf(s, c, t);
+          q[t] += p[s] * w[c];
+        }
+      }
+      for (uint32_t s : reach) visits[s] += q[s];
+      p.swap(q);
+    }
+    std::vector<uint32_t> cand;
+    double total = 0.0;
+    for (uint32_t s : reach)
+      if (klass(s) != 0) { cand.push_back(s); total += visits[s]; }
+    std::sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) {
+      if (visits[a] != visits[b]) return visits[a] > visits[b];
+      return bfsRank[a] < bfsRank[b];
+    });
+    // as many rows as the budget holds; but when a half-size set (two workgroups per CU then
+    // fit, twice the waves to hide the cold lookups) already covers 99.9 % of the modelled
+    // visits, take the half-size set
+    const uint32_t maxRows = std::min<uint64_t>(cand.size(), ldsTableMax / 512u);
+    const uint32_t halfRows = std::min<uint32_t>(maxRows, (79u * 1024u) / 512u);
+    auto coverage = [&](uint32_t rows) {
+      double c = 0.0;
+      for (uint32_t i = 0; i < rows; ++i) c += visits[cand[i]];
+      return total > 0.0 ? c / total : 1.0;
+    };
+    const uint32_t rows = coverage(halfRows) >= 0.999 ? halfRows : maxRows;
+    if (coverage(rows) < 0.5 && !forceHot) {
+      // no locality to exploit (e.g. a dense random DFA): the LDS rows would cost occupancy
+      // and catch little - leave the whole table to L2
+      img.tableKind = REDGPU_TAB_GLOBAL_U16;
+    } else {
+      for (uint32_t i = 0; i < rows; ++i) isHot[cand[i]] = 1;
+      img.nHot = rows;
+      img.hotCoveragePpm = uint32_t(coverage(rows) * 1e6);
+    }
+  }
+
+  // order: pure dead ends | non-accepting | accepting (stable in blob order); with hot rows
+  // the two middle groups are split cold | hot and hot | cold so the hot set is contiguous
   std::vector<uint32_t> order;
   order.reserve(reach.size());
-  for (int k = 0; k < 3; ++k) {
-    if (k == 1) img.nPureDead = uint32_t(order.size());
-    if (k == 2) img.firstAccept = uint32_t(order.size());
+  auto take = [&](int k, int hot) {
     for (uint32_t s : reach)
-      if (klass(s) == k)
+      if (klass(s) == k && (hot < 0 || int(isHot[s]) == hot))
         order.push_back(s);
+  };
+  take(0, -1);
+  img.nPureDead = uint32_t(order.size());
+  if (img.tableKind == REDGPU_TAB_HOT_U16) {
+    take(1, 0);
+    img.hotLo = uint32_t(order.size());
+    take(1, 1);
+    img.firstAccept = uint32_t(order.size());
+    take(2, 1);
+    take(2, 0);
+  } else {
+    take(1, -1);
+    img.firstAccept = uint32_t(order.size());
+    take(2, -1);
   }
   img.nStates = uint32_t(order.size());
   std::vector<uint32_t> newId(stateCnt, 0xffffffffu);
@@ -190,23 +285,6 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
     }
   }
 
-  // table placement
-  if (ldsTableMax == 0)
-    ldsTableMax = 144u * 1024u;
-  const uint64_t fused8 = uint64_t(img.nStates) * 256u;
-  const uint64_t fused16 = uint64_t(img.nStates) * 512u;
-  const uint64_t class16 = uint64_t(img.nStates) * nCls * 2u;
-  if (!forceGlobal && img.nStates <= 256 && fused8 <= ldsTableMax)
-    img.tableKind = REDGPU_TAB_LDS_FUSED_U8;
-  else if (!forceGlobal && img.nStates <= 65536 && fused16 <= ldsTableMax)
-    img.tableKind = REDGPU_TAB_LDS_FUSED_U16;
-  else if (!forceGlobal && img.nStates <= 65536 && class16 <= ldsTableMax)
-    img.tableKind = REDGPU_TAB_LDS_CLASS_U16;
-  else if (img.nStates <= 65536)
-    img.tableKind = REDGPU_TAB_GLOBAL_U16;
-  else
-    img.tableKind = REDGPU_TAB_GLOBAL_U32;
-
   auto put = [&](size_t idx, uint32_t v, uint32_t width) {
     if (width == 1) img.table[idx] = uint8_t(v);
     else if (width == 2) { uint16_t x = uint16_t(v); std::memcpy(&img.table[idx * 2], &x, 2); }
@@ -228,6 +306,17 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
     img.table.assign(size_t(img.nStates) * nCls * w, 0);
     for (size_t k = 0; k < img.next.size(); ++k)
       put(k, img.next[k], w);
+    if (img.tableKind == REDGPU_TAB_HOT_U16) {
+      // fused [hot state][byte] u16 rows behind the class table, 16-byte aligned
+      img.hotOff = uint32_t((img.table.size() + 15u) & ~size_t(15));
+      img.table.resize(size_t(img.hotOff) + size_t(img.nHot) * 512u, 0);
+      for (uint32_t hr = 0; hr < img.nHot; ++hr)
+        for (uint32_t b = 0; b < 256; ++b) {
+          const uint16_t x =
+              uint16_t(img.next[size_t(img.hotLo + hr) * nCls + img.equiv[b]]);
+          std::memcpy(&img.table[size_t(img.hotOff) + (size_t(hr) * 256 + b) * 2], &x, 2);
+        }
+    }
   }
   }
   errCode = REDGPU_OK;

@@ -44,6 +44,12 @@ struct DfaImage {
   // table chosen for the device
   uint32_t tableKind = 0;         // REDGPU_TAB_*
   std::vector<uint8_t> table;     // packed bytes of that table
+  // REDGPU_TAB_HOT_U16: device states [hotLo, hotLo + nHot) also have a fused [byte] u16 row
+  // at table[hotOff + (s - hotLo) * 512]; the kernels stage those rows into LDS.  The order is
+  // then  pure dead | cold non-accepting | hot non-accepting | hot accepting | cold accepting
+  // so that the hot set is ONE index range that straddles firstAccept.
+  uint32_t hotLo = 0, nHot = 0, hotOff = 0;
+  uint32_t hotCoveragePpm = 0;    // modelled share of visits landing on hot rows
 };
 
 // lib/Serializer.cpp:270-298, message text verbatim; nullptr when the header is good.
@@ -56,6 +62,6 @@ uint32_t calcChecksum(const void *ptr, size_t len);
 // Parses + bounds-checks + renumbers.  Returns "" on success, else the error message
 // (code: REDGPU_EAPI for a bad blob, REDGPU_ELIMIT for capacity).
 std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool forceGlobal,
-                       DfaImage &img, int &errCode);
+                       DfaImage &img, int &errCode, bool forceHot = false);
 
 } // namespace redgpu

@@ -24,6 +24,7 @@ struct DevDfa {
   uint32_t firstAccept;
   uint32_t leaderLen;
   uint32_t deadAbsorbing;
+  uint32_t hotLo, nHot, hotOff;  // REDGPU_TAB_HOT_U16 (dfa_image.h), else 0
 };
 
 // One batch of lines (device pointers).

@@ -90,6 +90,57 @@ template <> struct Tab<REDGPU_TAB_GLOBAL_U32> {
   }
 };
 
+// Hot rows (north star: "hot transition rows staged in LDS"): the n_hot most-visited states
+// have a fused [byte] u16 row in LDS - one ds_read_u16 per byte, no class lookup; every other
+// state goes through the class table in HBM/L2.  Hot states are one index range.
+template <> struct Tab<REDGPU_TAB_HOT_U16> {
+  static constexpr bool kInLds = false;
+  const uint16_t *t;
+  const uint16_t *hot;
+  const uint8_t *eq;
+  uint32_t nc, hotLo, nHot;
+  __device__ Tab(const uint8_t *tab, const uint8_t *equiv, uint32_t nClasses)
+      : t(reinterpret_cast<const uint16_t *>(tab)), hot(nullptr), eq(equiv), nc(nClasses),
+        hotLo(0), nHot(0) {}
+  __device__ __forceinline__ uint32_t next(uint32_t s, uint32_t byte) const {
+    const uint32_t hr = s - hotLo;
+    if (hr < nHot) return hot[(hr << 8) | byte];
+    return t[size_t(s) * nc + eq[byte]];
+  }
+};
+
+// What a workgroup stages behind its 512 bytes of equivalence map + leader, and the accessor
+// over it.  Whole table for the LDS kinds, the hot rows for REDGPU_TAB_HOT_U16, nothing else.
+template <int KIND>
+__host__ __device__ inline size_t ldsTableBytes(const DevDfa &d) {
+  if (Tab<KIND>::kInLds) return d.tableBytes;
+  if (KIND == REDGPU_TAB_HOT_U16) return size_t(d.nHot) * 512u;
+  return 0;
+}
+
+template <int KIND, int THREADS>
+__device__ __forceinline__ Tab<KIND> stageTab(const DevDfa &d, uint8_t *lds) {
+  uint8_t *eq = lds;
+  uint8_t *ldsTab = lds + 512;
+  for (uint32_t i = threadIdx.x; i < 512 / 4; i += THREADS)
+    reinterpret_cast<uint32_t *>(lds)[i] = reinterpret_cast<const uint32_t *>(d.equivLeader)[i];
+  const uint32_t n16 = uint32_t(ldsTableBytes<KIND>(d) / 16);
+  if (n16) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(
+        d.table + (KIND == REDGPU_TAB_HOT_U16 ? d.hotOff : 0u));
+    uint4 *dst = reinterpret_cast<uint4 *>(ldsTab);
+    for (uint32_t i = threadIdx.x; i < n16; i += THREADS) dst[i] = src[i];
+  }
+  __syncthreads();
+  Tab<KIND> tab(Tab<KIND>::kInLds ? ldsTab : d.table, eq, d.nClasses);
+  if constexpr (KIND == REDGPU_TAB_HOT_U16) {
+    tab.hot = reinterpret_cast<const uint16_t *>(ldsTab);
+    tab.hotLo = d.hotLo;
+    tab.nHot = d.nHot;
+  }
+  return tab;
+}
+
 struct LaneCtx {
   const uint8_t *eq;      // LDS: byte -> class
   const uint8_t *leader;  // LDS: class-space leader
@@ -318,17 +369,7 @@ k_generic(DevDfa d, Batch b, int verb, int style, int lead) {
   extern __shared__ __align__(16) uint8_t lds[];
   uint8_t *eq = lds;
   uint8_t *leader = lds + 256;
-  uint8_t *ldsTab = lds + 512;
-  for (uint32_t i = threadIdx.x; i < 512 / 4; i += kGenericThreads)
-    reinterpret_cast<uint32_t *>(lds)[i] = reinterpret_cast<const uint32_t *>(d.equivLeader)[i];
-  if (Tab<KIND>::kInLds) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(d.table);
-    uint4 *dst = reinterpret_cast<uint4 *>(ldsTab);
-    for (uint32_t i = threadIdx.x; i < d.tableBytes / 16; i += kGenericThreads) dst[i] = src[i];
-  }
-  __syncthreads();
-
-  const Tab<KIND> tab(Tab<KIND>::kInLds ? ldsTab : d.table, eq, d.nClasses);
+  const Tab<KIND> tab = stageTab<KIND, kGenericThreads>(d, lds);
   LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
             d.leaderLen};
 
@@ -558,16 +599,7 @@ k_collect(DevDfa d, Batch b, uint64_t cap, uint64_t *counts) {
   extern __shared__ __align__(16) uint8_t lds[];
   uint8_t *eq = lds;
   uint8_t *leader = lds + 256;
-  uint8_t *ldsTab = lds + 512;
-  for (uint32_t i = threadIdx.x; i < 512 / 4; i += kThreads)
-    reinterpret_cast<uint32_t *>(lds)[i] = reinterpret_cast<const uint32_t *>(d.equivLeader)[i];
-  if (Tab<KIND>::kInLds) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(d.table);
-    uint4 *dst = reinterpret_cast<uint4 *>(ldsTab);
-    for (uint32_t i = threadIdx.x; i < d.tableBytes / 16; i += kThreads) dst[i] = src[i];
-  }
-  __syncthreads();
-  const Tab<KIND> tab(Tab<KIND>::kInLds ? ldsTab : d.table, eq, d.nClasses);
+  const Tab<KIND> tab = stageTab<KIND, kThreads>(d, lds);
   LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
             d.leaderLen};
   const uint64_t step = uint64_t(gridDim.x) * kThreads;
@@ -646,16 +678,7 @@ k_matchall(DevDfa d, Batch b, uint64_t cap, uint64_t *counts, int lead) {
   extern __shared__ __align__(16) uint8_t lds[];
   uint8_t *eq = lds;
   uint8_t *leader = lds + 256;
-  uint8_t *ldsTab = lds + 512;
-  for (uint32_t i = threadIdx.x; i < 512 / 4; i += kThreads)
-    reinterpret_cast<uint32_t *>(lds)[i] = reinterpret_cast<const uint32_t *>(d.equivLeader)[i];
-  if (Tab<KIND>::kInLds) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(d.table);
-    uint4 *dst = reinterpret_cast<uint4 *>(ldsTab);
-    for (uint32_t i = threadIdx.x; i < d.tableBytes / 16; i += kThreads) dst[i] = src[i];
-  }
-  __syncthreads();
-  const Tab<KIND> tab(Tab<KIND>::kInLds ? ldsTab : d.table, eq, d.nClasses);
+  const Tab<KIND> tab = stageTab<KIND, kThreads>(d, lds);
   LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
             d.leaderLen};
   const uint64_t step = uint64_t(gridDim.x) * kThreads;
@@ -687,16 +710,7 @@ k_advance(DevDfa d, Batch b, uint32_t *state) {
   extern __shared__ __align__(16) uint8_t lds[];
   uint8_t *eq = lds;
   uint8_t *leader = lds + 256;
-  uint8_t *ldsTab = lds + 512;
-  for (uint32_t i = threadIdx.x; i < 512 / 4; i += kThreads)
-    reinterpret_cast<uint32_t *>(lds)[i] = reinterpret_cast<const uint32_t *>(d.equivLeader)[i];
-  if (Tab<KIND>::kInLds) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(d.table);
-    uint4 *dst = reinterpret_cast<uint4 *>(ldsTab);
-    for (uint32_t i = threadIdx.x; i < d.tableBytes / 16; i += kThreads) dst[i] = src[i];
-  }
-  __syncthreads();
-  const Tab<KIND> tab(Tab<KIND>::kInLds ? ldsTab : d.table, eq, d.nClasses);
+  const Tab<KIND> tab = stageTab<KIND, kThreads>(d, lds);
   LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
             d.leaderLen};
   const uint64_t step = uint64_t(gridDim.x) * kThreads;
@@ -713,9 +727,10 @@ k_advance(DevDfa d, Batch b, uint32_t *state) {
     }
     uint32_t s = state[line];
     if (s >= d.nStates) s = d.init;  // REDGPU_STATE_INITIAL (and any token that is not ours)
+    const bool stopDead = d.deadAbsorbing != 0;  // an absorbing dead end stays put: stop reading
     walkBytes(p, 0, n, [&](uint32_t byte, uint64_t) {
       s = tab.next(s, byte);
-      return true;
+      return !(stopDead && s < d.nPureDead);
     });
     state[line] = s;
     b.result[line] = c.resultOf(s);
@@ -732,13 +747,14 @@ hipError_t setLds(K kernel, size_t bytes) {
 template <int KIND>
 hipError_t launchGeneric(const DevDfa &d, const Batch &b, int verb, int style, int lead,
                          const LaunchCfg &cfg, hipStream_t stream) {
-  constexpr int kThreads = Tab<KIND>::kInLds ? 1024 : 256;
-  const size_t ldsBytes = 512 + (Tab<KIND>::kInLds ? size_t(d.tableBytes) : 0);
+  constexpr bool kLds = Tab<KIND>::kInLds || KIND == REDGPU_TAB_HOT_U16;
+  constexpr int kThreads = kLds ? 1024 : 256;
+  const size_t ldsBytes = 512 + ldsTableBytes<KIND>(d);
   hipError_t e = setLds(k_generic<KIND, kThreads>, ldsBytes);
   if (e != hipSuccess) return e;
   uint64_t blocks = (b.n + kThreads - 1) / kThreads;
   // an LDS-resident table is re-staged per block: keep the grid near one wave of blocks
-  const uint64_t perCu = Tab<KIND>::kInLds ? (ldsBytes <= 80 * 1024 ? 2 : 1) : 8;
+  const uint64_t perCu = kLds ? (ldsBytes <= 80 * 1024 ? 2 : 1) : 8;
   const uint64_t cap = uint64_t(cfg.numCUs) * perCu;
   if (blocks > cap) blocks = cap;
   if (blocks == 0) blocks = 1;
@@ -750,12 +766,13 @@ hipError_t launchGeneric(const DevDfa &d, const Batch &b, int verb, int style, i
 template <int KIND>
 hipError_t launchCollectK(const DevDfa &d, const Batch &b, uint64_t cap, uint64_t *counts,
                           const LaunchCfg &cfg, hipStream_t stream) {
-  constexpr int kThreads = Tab<KIND>::kInLds ? 1024 : 256;
-  const size_t ldsBytes = 512 + (Tab<KIND>::kInLds ? size_t(d.tableBytes) : 0);
+  constexpr bool kLds = Tab<KIND>::kInLds || KIND == REDGPU_TAB_HOT_U16;
+  constexpr int kThreads = kLds ? 1024 : 256;
+  const size_t ldsBytes = 512 + ldsTableBytes<KIND>(d);
   hipError_t e = setLds(k_collect<KIND, kThreads>, ldsBytes);
   if (e != hipSuccess) return e;
   uint64_t blocks = (b.n + kThreads - 1) / kThreads;
-  const uint64_t perCu = Tab<KIND>::kInLds ? (ldsBytes <= 80 * 1024 ? 2 : 1) : 8;
+  const uint64_t perCu = kLds ? (ldsBytes <= 80 * 1024 ? 2 : 1) : 8;
   const uint64_t capBlocks = uint64_t(cfg.numCUs) * perCu;
   if (blocks > capBlocks) blocks = capBlocks;
   if (blocks == 0) blocks = 1;
@@ -767,12 +784,13 @@ hipError_t launchCollectK(const DevDfa &d, const Batch &b, uint64_t cap, uint64_
 template <int KIND>
 hipError_t launchMatchAllK(const DevDfa &d, const Batch &b, uint64_t cap, uint64_t *counts,
                            int lead, const LaunchCfg &cfg, hipStream_t stream) {
-  constexpr int kThreads = Tab<KIND>::kInLds ? 1024 : 256;
-  const size_t ldsBytes = 512 + (Tab<KIND>::kInLds ? size_t(d.tableBytes) : 0);
+  constexpr bool kLds = Tab<KIND>::kInLds || KIND == REDGPU_TAB_HOT_U16;
+  constexpr int kThreads = kLds ? 1024 : 256;
+  const size_t ldsBytes = 512 + ldsTableBytes<KIND>(d);
   hipError_t e = setLds(k_matchall<KIND, kThreads>, ldsBytes);
   if (e != hipSuccess) return e;
   uint64_t blocks = (b.n + kThreads - 1) / kThreads;
-  const uint64_t perCu = Tab<KIND>::kInLds ? (ldsBytes <= 80 * 1024 ? 2 : 1) : 8;
+  const uint64_t perCu = kLds ? (ldsBytes <= 80 * 1024 ? 2 : 1) : 8;
   const uint64_t capBlocks = uint64_t(cfg.numCUs) * perCu;
   if (blocks > capBlocks) blocks = capBlocks;
   if (blocks == 0) blocks = 1;
@@ -784,12 +802,13 @@ hipError_t launchMatchAllK(const DevDfa &d, const Batch &b, uint64_t cap, uint64
 template <int KIND>
 hipError_t launchAdvanceK(const DevDfa &d, const Batch &b, uint32_t *state, const LaunchCfg &cfg,
                           hipStream_t stream) {
-  constexpr int kThreads = Tab<KIND>::kInLds ? 1024 : 256;
-  const size_t ldsBytes = 512 + (Tab<KIND>::kInLds ? size_t(d.tableBytes) : 0);
+  constexpr bool kLds = Tab<KIND>::kInLds || KIND == REDGPU_TAB_HOT_U16;
+  constexpr int kThreads = kLds ? 1024 : 256;
+  const size_t ldsBytes = 512 + ldsTableBytes<KIND>(d);
   hipError_t e = setLds(k_advance<KIND, kThreads>, ldsBytes);
   if (e != hipSuccess) return e;
   uint64_t blocks = (b.n + kThreads - 1) / kThreads;
-  const uint64_t perCu = Tab<KIND>::kInLds ? (ldsBytes <= 80 * 1024 ? 2 : 1) : 8;
+  const uint64_t perCu = kLds ? (ldsBytes <= 80 * 1024 ? 2 : 1) : 8;
   const uint64_t capBlocks = uint64_t(cfg.numCUs) * perCu;
   if (blocks > capBlocks) blocks = capBlocks;
   if (blocks == 0) blocks = 1;
@@ -861,6 +880,8 @@ hipError_t launchCollect(const DevDfa &d, const Batch &b, uint64_t cap, uint64_t
     return launchCollectK<REDGPU_TAB_LDS_CLASS_U16>(d, b, cap, counts, cfg, stream);
   case REDGPU_TAB_GLOBAL_U16:
     return launchCollectK<REDGPU_TAB_GLOBAL_U16>(d, b, cap, counts, cfg, stream);
+  case REDGPU_TAB_HOT_U16:
+    return launchCollectK<REDGPU_TAB_HOT_U16>(d, b, cap, counts, cfg, stream);
   default:
     return launchCollectK<REDGPU_TAB_GLOBAL_U32>(d, b, cap, counts, cfg, stream);
   }
@@ -872,6 +893,7 @@ hipError_t launchCollect(const DevDfa &d, const Batch &b, uint64_t cap, uint64_t
   case REDGPU_TAB_LDS_FUSED_U16: return CALL(REDGPU_TAB_LDS_FUSED_U16);                   \
   case REDGPU_TAB_LDS_CLASS_U16: return CALL(REDGPU_TAB_LDS_CLASS_U16);                   \
   case REDGPU_TAB_GLOBAL_U16: return CALL(REDGPU_TAB_GLOBAL_U16);                         \
+  case REDGPU_TAB_HOT_U16: return CALL(REDGPU_TAB_HOT_U16);                               \
   default: return CALL(REDGPU_TAB_GLOBAL_U32);                                            \
   }
 
@@ -997,6 +1019,8 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
     return launchGeneric<REDGPU_TAB_LDS_CLASS_U16>(d, b, verb, style, lead, cfg, stream);
   case REDGPU_TAB_GLOBAL_U16:
     return launchGeneric<REDGPU_TAB_GLOBAL_U16>(d, b, verb, style, lead, cfg, stream);
+  case REDGPU_TAB_HOT_U16:
+    return launchGeneric<REDGPU_TAB_HOT_U16>(d, b, verb, style, lead, cfg, stream);
   default:
     return launchGeneric<REDGPU_TAB_GLOBAL_U32>(d, b, verb, style, lead, cfg, stream);
   }

@@ -210,7 +210,7 @@ int redgpu_dfa_create(const void *reda, size_t len, const redgpu_opts *opts, red
   if (!h) return fail(REDGPU_ELIMIT, "out of host memory");
   int code = REDGPU_OK;
   std::string err = buildImage(reda, len, o.lds_table_max, (o.flags & REDGPU_F_FORCE_GLOBAL) != 0,
-                               h->img, code);
+                               h->img, code, (o.flags & REDGPU_F_FORCE_HOT) != 0);
   if (!err.empty()) {
     delete h;
     return fail(code, err);
@@ -274,6 +274,9 @@ int redgpu_dfa_create(const void *reda, size_t len, const redgpu_opts *opts, red
   d.firstAccept = img.firstAccept;
   d.leaderLen = img.leaderLen;
   d.deadAbsorbing = img.deadAbsorbing ? 1 : 0;
+  d.hotLo = img.hotLo;
+  d.nHot = img.nHot;
+  d.hotOff = img.hotOff;
   *out = h;
   return REDGPU_OK;
 }
@@ -306,6 +309,10 @@ int redgpu_dfa_info(const redgpu_dfa *h, redgpu_info *out) {
   out->checksum = img.checksum;
   out->fast_path = (img.tableKind == REDGPU_TAB_LDS_FUSED_U8 && img.deadAbsorbing &&
                     !(h->flags & REDGPU_F_FORCE_GENERIC)) ? 1 : 0;
+  out->n_hot = img.nHot;
+  out->hot_lo = img.hotLo;
+  out->hot_coverage_ppm = img.hotCoveragePpm;
+  out->reserved = 0;
   return REDGPU_OK;
 }
 

@@ -79,6 +79,19 @@ URI_REGEX = (r"(https?|ftps?|file|wss?|sftp|ssh|git|ldaps?)://"
              r"(\?[A-Za-z0-9._~%!$&'()*+,;=:@/?-]*)?(#[A-Za-z0-9._~%-]*)?")
 URI_PLANT = b"https://ab-c.example.com:8080/p/x.y?q=1&r=%20#frag "
 
+# BASELINE.json configs[4]'s real-regex stand-in (SURVEY 8d "C5" alternative): 20 schemes,
+# userinfo, names / IPv4 / bracketed IPv6, loose start, ignore case -> 3,254 states and 35
+# classes through the reference compiler: a class table of 228 KB that does NOT fit LDS whole.
+_H16 = r"[0-9a-f]{1,4}"
+URI_V6_REGEX = (
+    r"(https?|ftps?|file|wss?|sftp|ssh|git|ldaps?|mailto|news|nntp|telnet|gopher|irc|rtsp|smb|"
+    r"nfs|svn|s3|gs)://([a-z0-9._-]+@)?"
+    r"(([a-z0-9-]+\.)+[a-z]{2,6}|[0-9]{1,3}\.[0-9]{1,3}\.[0-9]{1,3}\.[0-9]{1,3}|"
+    r"\[((H:){7}H|(H:){1,6}:H|::(H:){0,5}H)\])"
+    r"(:[0-9]{1,5})?(/[A-Za-z0-9._~%!$&'()*+,;=:@/-]*)?"
+    r"(\?[A-Za-z0-9._~%!$&'()*+,;=:@/?-]*)?(#[A-Za-z0-9._~%-]*)?").replace("H", _H16)
+URI_V6_PLANT = b"SFTP://bob@[2001:db8:0:1:0:0:0:2f]:2222/srv/data?x=1#top "
+
 LOG_LEVELS = ["ERROR", "WARN", "INFO", "DEBUG", "FATAL"]
 LOG_SUBSYS = ["net", "disk", "auth", "db", "cache", "sched", "rpc", "dns", "tls", "fs",
               "mem", "cpu", "gpu", "raid", "ntp", "smtp", "http", "kern", "init", "cron"]

@@ -330,6 +330,7 @@ def config_dfas():
     d["newyork"] = O.ref_compile([("New", 1, LS), ("New York", 2, LS), ("York", 3, LS)])
     d["aab"] = O.ref_compile([("aab", 1, 0)])
     d["dotstar_err"] = O.ref_compile([(".*error", 1, 0)])
+    d["uri_v6"] = O.ref_compile([(W.URI_V6_REGEX, 1, O.F_LOOSE_START | O.F_IGNORE_CASE)])
     return d
 
 
@@ -342,6 +343,9 @@ def inputs_for(name: str, rng: np.random.Generator):
     ins += heads[:10] + [h[:-3] for h in heads[10:20]] + [b"x" + h for h in heads[20:24]]
     ins += [W.URI_PLANT, b"see " + W.URI_PLANT, b"http://1.2.3.4", b"ftp://a.bc/",
             b"http://a.b", b"xxhttps://a.io:80/?#", b"HTTP://A.COM"]
+    if name == "uri_v6":  # added with that DFA; the older sets keep their recorded inputs
+        ins += [W.URI_V6_PLANT, b"go " + W.URI_V6_PLANT + b"tail", b"ssh://[::1]:22/",
+                b"Gopher://U@[1:2:3:4:5:6:7:8]", b"s3://bucket.name.io/k?v#f", b"nfs://[1::]"]
     for _ in range(700):
         n = int(rng.integers(0, 200))
         ins.append(W.ALPHABET47[rng.integers(0, 47, n)].tobytes())
@@ -357,9 +361,11 @@ def inputs_for(name: str, rng: np.random.Generator):
     return ins
 
 
-def gen_vectors():
+def gen_vectors(only=None):
     dfas = config_dfas()
     for name, blob in dfas.items():
+        if only and name not in only:
+            continue
         with open(os.path.join(GOLD, "dfas", name + ".reda"), "wb") as f:
             f.write(blob)
         info = O.CpuOracle(blob).info
@@ -540,6 +546,9 @@ def main():
     for name, fn in steps.items():
         if not only or name in only:
             fn()
+    for arg in only:  # "vectors:NAME[,NAME]" regenerates the vectors of those DFAs only
+        if arg.startswith("vectors:"):
+            gen_vectors(set(arg.split(":", 1)[1].split(",")))
 
 
 if __name__ == "__main__":

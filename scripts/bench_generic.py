@@ -37,3 +37,13 @@ timeit(lambda: one_amd.match_batch(exe5, d5, 4, 0, stride=L5, n=n5), n5 * L5, "c
 n6, L6 = 1 << 18, 1024
 d6 = torch.randint(0, 256, (n6 * L6,), dtype=torch.uint8, device="cuda")
 timeit(lambda: one_amd.match_batch(exe5, d6, 4, 0, stride=L6, n=n6), n6 * L6, "SYN-4K 2^18 x 1 KiB", it=3)
+# real-regex big DFA (class table larger than LDS): random bytes and text with planted URLs
+exe7 = one_amd.Executable(load_dfa("uri_v6"))
+print("uri_v6:", exe7.info)
+timeit(lambda: one_amd.match_batch(exe7, d6, 4, 0, stride=L6, n=n6), n6 * L6, "URI-V6 (3254 st / 35 cls) 2^18 x 1 KiB random bytes", it=3)
+n8, L8 = 1 << 20, 256
+t8 = W.fixed_lines(n8, L8, 8, alphabet=True, plant=W.URI_V6_PLANT, plant_every=8, plant_at=32)
+d8 = torch.from_numpy(t8).cuda()
+timeit(lambda: one_amd.match_batch(exe7, d8, 4, 0, stride=L8, n=n8), n8 * L8, "URI-V6 2^20 x 256 B text, URL planted every 8th line", it=3)
+exe9 = one_amd.Executable(load_dfa("log100"))
+timeit(lambda: one_amd.match_batch(exe9, d8, 4, 0, stride=L8, n=n8), n8 * L8, "LOG-100 match<Last,false> same text (dies early)", it=3)

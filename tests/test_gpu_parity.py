@@ -158,6 +158,50 @@ def test_random_dfas_vs_oracle(seed):
             assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee)
 
 
+@pytest.mark.parametrize("rows", [0, 8, 40, 200])
+def test_hot_row_tables_vs_oracle(rows):
+    """REDGPU_TAB_HOT_U16: hot states' fused rows in LDS, the rest in the class table in L2.
+    A random DFA whose walk keeps crossing between hot and cold states (the LDS budget is set
+    so that only `rows` rows fit; 0 = default budget), every verb and style, against the
+    oracle; then the two reference-compiled big DFAs at several budgets."""
+    blob = random_dfa(2500, 48, 77, dead_frac=0.01, accept_frac=0.2)  # 240 KB class table
+    # a dense random DFA has no locality: force_hot keeps the hot rows anyway
+    exe = one_amd.Executable(blob, force_hot=True, lds_table_max=(rows or 100) * 512)
+    cpu = O.CpuOracle(blob)
+    assert exe.info["table_kind"] == 6 and exe.info["n_hot"] == (rows or 100)
+    rng = np.random.default_rng(rows)
+    lens = rng.integers(0, 200, 4000)
+    offsets = np.zeros(len(lens) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    data = rng.integers(0, 256, int(offsets[-1]), dtype=np.uint8)
+    for si in range(1, 6):
+        for lead in (0, 1):
+            for verb, fn in (("match", one_amd.match_batch), ("search", one_amd.search_batch)):
+                er, es, ee = cpu.batch(verb, si, lead, data, offsets=offsets, threads=4)
+                r, s, e = fn(exe, data, si, lead, offsets=offsets)
+                assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee)
+            assert np.array_equal(one_amd.check_batch(exe, data, si, lead, offsets=offsets),
+                                  cpu.batch("check", si, lead, data, offsets=offsets)[0])
+            assert np.array_equal(one_amd.scan_batch(exe, data, si, lead, offsets=offsets),
+                                  cpu.batch("scan", si, lead, data, offsets=offsets, threads=4)[0])
+    state = np.full(len(lens), one_amd.STATE_INITIAL, dtype=np.uint32)
+    ostate = np.full(len(lens), O.STATE_INITIAL, dtype=np.uint32)
+    assert np.array_equal(one_amd.advance_batch(exe, data, state, offsets=offsets),
+                          cpu.advance_batch(data, ostate, offsets=offsets))
+    got = one_amd.match_all_batch(exe, data, 4, True, offsets=offsets)
+    exp = cpu.match_all_batch(data, 4, do_leader=True, offsets=offsets)
+    assert np.array_equal(got[0], exp[0])
+    for name in ("log100", "uri_v6"):
+        vec = load_vectors(name)
+        exe = one_amd.Executable(load_dfa(name), **({"lds_table_max": rows * 512} if rows else {}))
+        assert exe.info["table_kind"] == 6
+        for lead in (0, 1):
+            r, s, e = one_amd.match_batch(exe, vec["data"], 4, lead, offsets=vec["offsets"])
+            key = "match_4_%d_" % lead
+            assert np.array_equal(r, vec[key + "res"]) and np.array_equal(s, vec[key + "start"])
+            assert np.array_equal(e, vec[key + "end"])
+
+
 def test_edge_cases():
     exe = one_amd.Executable(load_dfa("err"))
     cpu = O.CpuOracle(load_dfa("err"))

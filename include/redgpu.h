@@ -70,9 +70,11 @@ typedef struct redgpu_opts {
 #define REDGPU_TAB_LDS_CLASS_U16  3 /* [state][class] u16 + equivalence map, both in LDS */
 #define REDGPU_TAB_GLOBAL_U16     4 /* [state][class] u16 in HBM/L2, equivalence map in LDS */
 #define REDGPU_TAB_GLOBAL_U32     5 /* [state][class] u32 in HBM/L2, equivalence map in LDS */
-#define REDGPU_TAB_HOT_U16        6 /* [state][class] u16 in HBM/L2 for every state, plus fused
-                                       [hot state][byte] u16 rows of the n_hot most-visited
-                                       states in LDS (device states [hot_lo, hot_lo + n_hot)) */
+#define REDGPU_TAB_HOT_ROWS       6 /* [state][class] u16 in HBM/L2 for every state, plus a 64 KB
+                                       [hot index][byte] u8 table in LDS over the n_hot (<= 254)
+                                       most-visited states (device states [hot_lo, hot_lo +
+                                       n_hot)): entry = hot index of the target, 255 = the
+                                       target is not hot (look it up in the class table) */
 
 typedef struct redgpu_info {
   uint32_t format;        /* 1, 2, 4: FileHeader.format_ (include/Serializer.h:34-40,47) */
@@ -88,11 +90,13 @@ typedef struct redgpu_info {
   int32_t  device;
   uint32_t checksum;      /* FileHeader.checksum_ */
   uint32_t fast_path;     /* 1 if the fixed-stride specialised kernels apply to this DFA */
-  uint32_t n_hot;         /* REDGPU_TAB_HOT_U16: rows resident in LDS (else 0) */
-  uint32_t hot_lo;        /* REDGPU_TAB_HOT_U16: first device state with an LDS row */
-  uint32_t hot_coverage_ppm; /* REDGPU_TAB_HOT_U16: share of the modelled visits (random-byte
+  uint32_t n_hot;         /* REDGPU_TAB_HOT_ROWS: rows resident in LDS (else 0) */
+  uint32_t hot_lo;        /* REDGPU_TAB_HOT_ROWS: first device state with an LDS row */
+  uint32_t hot_coverage_ppm; /* REDGPU_TAB_HOT_ROWS: share of the modelled visits (random-byte
                              walk from the initial state) that land on LDS rows, per million */
-  uint32_t reserved;
+  uint32_t early_death;   /* 1 if the same model sees most walks reach a pure dead end within 16
+                             bytes (an anchored DFA on arbitrary text): such DFAs keep the
+                             early-exit kernels */
 } redgpu_info;
 
 /* Replaces checkHeader (include/Serializer.h:109, lib/Serializer.cpp:270-298): returns

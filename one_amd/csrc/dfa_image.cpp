@@ -173,8 +173,8 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
       img.tableKind = REDGPU_TAB_LDS_FUSED_U16;
     else if (!forceGlobal && nR <= 65536 && class16 <= ldsTableMax)
       img.tableKind = REDGPU_TAB_LDS_CLASS_U16;
-    else if (!forceGlobal && nR <= 65536 && ldsTableMax >= 8u * 512u)
-      img.tableKind = REDGPU_TAB_HOT_U16;
+    else if (!forceGlobal && nR <= 65536 && ldsTableMax >= 8u * 256u)
+      img.tableKind = REDGPU_TAB_HOT_ROWS;
     else if (nR <= 65536)
       img.tableKind = REDGPU_TAB_GLOBAL_U16;
     else
@@ -187,7 +187,7 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
   // model never reaches, e.g. deep inside a signature - go by breadth-first distance from
   // the initial state.  Pure dead ends are never looked up (the walk stops there).
   std::vector<uint8_t> isHot(stateCnt, 0);
-  if (img.tableKind == REDGPU_TAB_HOT_U16) {
+  if (img.tableKind == REDGPU_TAB_HOT_ROWS) {
     std::vector<double> w(nCls, 0.0);
     for (uint32_t b = 0; b < 256; ++b) {
       double wb = 0.5 / 256.0;
@@ -196,6 +196,7 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
     }
     std::vector<double> p(stateCnt, 0.0), q(stateCnt, 0.0), visits(stateCnt, 0.0);
     p[rawInit] = 1.0;
+    double died = 0.0;  // mass that has reached a pure dead end so far
     for (int step = 0; step < 64; ++step) {
       std::fill(q.begin(), q.end(), 0.0);
       for (uint32_t s : reach) {
@@ -206,7 +207,11 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
           q[t] += p[s] * w[c];
         }
       }
-      for (uint32_t s : reach) visits[s] += q[s];
+      for (uint32_t s : reach) {
+        visits[s] += q[s];
+        if (klass(s) == 0) died += q[s];
+      }
+      if (step == 15) img.earlyDeath = died > 0.5;
       p.swap(q);
     }
     std::vector<uint32_t> cand;
@@ -217,23 +222,26 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
       if (visits[a] != visits[b]) return visits[a] > visits[b];
       return bfsRank[a] < bfsRank[b];
     });
-    // as many rows as the budget holds; but when a half-size set (two workgroups per CU then
-    // fit, twice the waves to hide the cold lookups) already covers 99.9 % of the modelled
-    // visits, take the half-size set
-    const uint32_t maxRows = std::min<uint64_t>(cand.size(), ldsTableMax / 512u);
-    const uint32_t halfRows = std::min<uint32_t>(maxRows, (79u * 1024u) / 512u);
+    // as many rows as the budget holds, never more than 254: hot states are indexed with one
+    // byte, 255 means "not hot" and index 0 may stand for the pure dead ends
+    const uint32_t maxRows =
+        std::min<uint64_t>(254u, std::min<uint64_t>(cand.size(), ldsTableMax / 256u));
     auto coverage = [&](uint32_t rows) {
       double c = 0.0;
       for (uint32_t i = 0; i < rows; ++i) c += visits[cand[i]];
       return total > 0.0 ? c / total : 1.0;
     };
-    const uint32_t rows = coverage(halfRows) >= 0.999 ? halfRows : maxRows;
+    const uint32_t rows = maxRows;
     if (coverage(rows) < 0.5 && !forceHot) {
       // no locality to exploit (e.g. a dense random DFA): the LDS rows would cost occupancy
       // and catch little - leave the whole table to L2
       img.tableKind = REDGPU_TAB_GLOBAL_U16;
     } else {
       for (uint32_t i = 0; i < rows; ++i) isHot[cand[i]] = 1;
+      if (!isHot[rawInit] && klass(rawInit) != 0 && rows) {
+        isHot[cand[rows - 1]] = 0;  // the initial state always has a row
+        isHot[rawInit] = 1;
+      }
       img.nHot = rows;
       img.hotCoveragePpm = uint32_t(coverage(rows) * 1e6);
     }
@@ -250,7 +258,7 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
   };
   take(0, -1);
   img.nPureDead = uint32_t(order.size());
-  if (img.tableKind == REDGPU_TAB_HOT_U16) {
+  if (img.tableKind == REDGPU_TAB_HOT_ROWS) {
     take(1, 0);
     img.hotLo = uint32_t(order.size());
     take(1, 1);
@@ -306,15 +314,22 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
     img.table.assign(size_t(img.nStates) * nCls * w, 0);
     for (size_t k = 0; k < img.next.size(); ++k)
       put(k, img.next[k], w);
-    if (img.tableKind == REDGPU_TAB_HOT_U16) {
-      // fused [hot state][byte] u16 rows behind the class table, 16-byte aligned
-      img.hotOff = uint32_t((img.table.size() + 15u) & ~size_t(15));
-      img.table.resize(size_t(img.hotOff) + size_t(img.nHot) * 512u, 0);
+    if (img.tableKind == REDGPU_TAB_HOT_ROWS) {
+      // [hot index][byte] u8 behind the class table, 16-byte aligned; unused rows and the
+      // sink row 255 are all 255; with reachable (absorbing) pure dead ends hot index 0 is
+      // their shared all-zero row
+      img.hotShift = (img.nPureDead > 0 && img.deadAbsorbing) ? 1 : 0;
+      img.hot8Off = uint32_t((img.table.size() + 15u) & ~size_t(15));
+      img.table.resize(size_t(img.hot8Off) + 65536u, 0xff);
+      uint8_t *t8 = &img.table[img.hot8Off];
+      if (img.hotShift) std::memset(t8, 0, 256);
       for (uint32_t hr = 0; hr < img.nHot; ++hr)
         for (uint32_t b = 0; b < 256; ++b) {
-          const uint16_t x =
-              uint16_t(img.next[size_t(img.hotLo + hr) * nCls + img.equiv[b]]);
-          std::memcpy(&img.table[size_t(img.hotOff) + (size_t(hr) * 256 + b) * 2], &x, 2);
+          const uint32_t t = img.next[size_t(img.hotLo + hr) * nCls + img.equiv[b]];
+          uint8_t v = 0xff;
+          if (img.hotShift && t < img.nPureDead) v = 0;
+          else if (t - img.hotLo < img.nHot) v = uint8_t(t - img.hotLo + img.hotShift);
+          t8[size_t(hr + img.hotShift) * 256 + b] = v;
         }
     }
   }

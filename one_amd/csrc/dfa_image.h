@@ -44,12 +44,17 @@ struct DfaImage {
   // table chosen for the device
   uint32_t tableKind = 0;         // REDGPU_TAB_*
   std::vector<uint8_t> table;     // packed bytes of that table
-  // REDGPU_TAB_HOT_U16: device states [hotLo, hotLo + nHot) also have a fused [byte] u16 row
-  // at table[hotOff + (s - hotLo) * 512]; the kernels stage those rows into LDS.  The order is
-  // then  pure dead | cold non-accepting | hot non-accepting | hot accepting | cold accepting
+  // REDGPU_TAB_HOT_ROWS: the class table (u16) is followed, at table[hot8Off], by a 64 KB u8
+  // table [hot index][byte] -> hot index of the target, 255 = target outside the hot set (row
+  // 255 is an absorbing sink).  Hot index of device state s in [hotLo, hotLo + nHot) is
+  // s - hotLo + hotShift; with hotShift = 1 hot index 0 stands for every pure dead end (one
+  // absorbing all-zero row).  The order is then
+  //   pure dead | cold non-accepting | hot non-accepting | hot accepting | cold accepting
   // so that the hot set is ONE index range that straddles firstAccept.
-  uint32_t hotLo = 0, nHot = 0, hotOff = 0;
+  uint32_t hotLo = 0, nHot = 0, hot8Off = 0, hotShift = 0;
   uint32_t hotCoveragePpm = 0;    // modelled share of visits landing on hot rows
+  bool     earlyDeath = false;    // the model's walk is in a pure dead end within 16 bytes
+                                  // more often than not (anchored DFA on arbitrary text)
 };
 
 // lib/Serializer.cpp:270-298, message text verbatim; nullptr when the header is good.

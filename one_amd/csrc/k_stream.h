@@ -137,7 +137,44 @@ struct BlockRegs {
 };
 
 // HALVES = 2: 128-byte blocks (stride % 128 == 0); HALVES = 1: 64-byte blocks (stride % 64 == 0)
-template <int MODE, int HALVES, int THREADS>
+//
+// HOT = true (REDGPU_TAB_HOT_ROWS DFAs): the LDS table is the 64 KB
+// [hot index][byte] u8 table of dfa_image.h - entries are hot indices (index 0 = any pure dead
+// end when hotShift is 1), 255 = "this transition leaves the hot set", row 255 an absorbing sink.  The fast walk is unchanged; after
+// every 64-byte half-block the wave asks whether any of its lanes sits in the sink, and if so
+// those lanes re-walk that half-block from its saved entry state in slowHalf() - hot steps
+// through the LDS table, cold steps through the class table in L2 - and skip the fold.  Line-level
+// states (accS, the carried cold state g) are GLOBAL device state ids in this mode.
+constexpr uint32_t kNoState = 0xffffffffu;
+
+struct SlowBook {  // by value in and out: nothing of the fast path has its address taken
+  uint32_t st, accS, endv, startv;
+};
+
+template <int MODE>
+__device__ __noinline__ SlowBook slowHalf(const DevDfa &d, const uint8_t *tab8, const uint8_t *p,
+                                          uint32_t off, SlowBook in) {
+  uint32_t st = in.st, accS = in.accS, endv = in.endv, startv = in.startv;
+  constexpr bool kAcc = MODE == kSmLastStartEnd || MODE == kSmLastEnd;
+  constexpr bool kStart = MODE == kSmLastStartEnd || MODE == kSmFullStart;
+  const uint16_t *cls = reinterpret_cast<const uint16_t *>(d.table);
+  const uint8_t *eq = d.equivLeader;
+  for (uint32_t k = 0; k < 64; ++k) {
+    const uint32_t byte = p[k];
+    const uint32_t was = st;
+    const uint32_t hr = st - d.hotLo;
+    const uint32_t nx = hr < d.nHot ? uint32_t(tab8[((hr + d.hotShift) << 8) | byte]) : 255u;
+    if (nx != 255u)
+      st = (d.hotShift && nx == 0) ? 0u : d.hotLo + nx - d.hotShift;
+    else
+      st = cls[size_t(st) * d.nClasses + eq[byte]];
+    if (kStart && was == d.init && st != was) startv = off + k;
+    if (kAcc && st >= d.firstAccept) { accS = st; endv = off + k + 1; }
+  }
+  return SlowBook{st, accS, endv, startv};
+}
+
+template <int MODE, int HALVES, int THREADS, bool HOT = false>
 __global__ void __launch_bounds__(THREADS)
 k_stream(DevDfa d, Batch io) {
   constexpr uint32_t BLK = 64 * HALVES;
@@ -148,7 +185,19 @@ k_stream(DevDfa d, Batch io) {
   uint8_t *tab = lds;
   int32_t *ldsRes = reinterpret_cast<int32_t *>(lds + kStreamTabBytes);
 
-  const uint32_t init = d.init, firstAccept = d.firstAccept;
+  // HOT: the walk runs in hot-index space (init / firstAccept relative to hotLo; a cold initial
+  // state gets an index no lane can hold)
+  const uint32_t init =
+      HOT ? (d.init - d.hotLo < d.nHot ? d.init - d.hotLo + d.hotShift : 0x1ffu) : d.init;
+  const uint32_t firstAccept = HOT ? d.firstAccept - d.hotLo + d.hotShift : d.firstAccept;
+  // HOT: global state id <-> hot index (255 = not hot; index 0 = dead when hotShift)
+  auto toHot = [&](uint32_t st) -> uint32_t {
+    if (d.hotShift && st < d.nPureDead) return 0u;
+    return st - d.hotLo < d.nHot ? st - d.hotLo + d.hotShift : 255u;
+  };
+  auto toGlobal = [&](uint32_t idx) -> uint32_t {
+    return (d.hotShift && idx == 0) ? 0u : d.hotLo + idx - d.hotShift;
+  };
   const uint32_t lineLen = uint32_t(io.stride);
   const uint32_t R = lineLen / BLK;  // blocks per line
   const uint64_t linesPerTile = uint64_t(THREADS) * CH;
@@ -159,15 +208,15 @@ k_stream(DevDfa d, Batch io) {
   const uint64_t Q = myTiles * R;
 
   {
-    const uint4 *src = reinterpret_cast<const uint4 *>(d.table);
-    const uint32_t n16 = d.tableBytes / 16;
+    const uint4 *src = reinterpret_cast<const uint4 *>(d.table + (HOT ? d.hot8Off : 0u));
+    const uint32_t n16 = HOT ? kStreamTabBytes / 16 : d.tableBytes / 16;
     uint4 v[kStreamTabBytes / 16 / THREADS];
 #pragma unroll
     for (uint32_t k = 0; k < kStreamTabBytes / 16 / THREADS; ++k) {
       const uint32_t i = k * THREADS + threadIdx.x;
       v[k] = i < n16 ? src[i] : make_uint4(0, 0, 0, 0);
     }
-    const int32_t myRes = threadIdx.x < d.nStates ? d.result[threadIdx.x] : 0;
+    const int32_t myRes = HOT ? 0 : threadIdx.x < d.nStates ? d.result[threadIdx.x] : 0;
     uint4 *dst = reinterpret_cast<uint4 *>(tab);
 #pragma unroll
     for (uint32_t k = 0; k < kStreamTabBytes / 16 / THREADS; ++k) dst[k * THREADS + threadIdx.x] = v[k];
@@ -212,6 +261,7 @@ k_stream(DevDfa d, Batch io) {
   };
 
   uint32_t s[CH], accS[CH], endv[CH], startv[CH];
+  uint32_t g[CH];  // HOT: global id of the lane's state while it is outside the hot set
   uint64_t mA[CH], mB[CH];
   uint64_t tile = blockIdx.x;
   uint32_t r = 0;
@@ -224,14 +274,27 @@ k_stream(DevDfa d, Batch io) {
       for (int c = 0; c < CH; ++c) {
         s[c] = init; accS[c] = 0; endv[c] = 0; startv[c] = 0;
         mA[c] = ~0ull; mB[c] = ~0ull;
-        if (MODE == kSmAdvance) s[c] = blk[c].st < d.nStates ? blk[c].st : init;
+        g[c] = kNoState;
+        if (MODE == kSmAdvance && !HOT) s[c] = blk[c].st < d.nStates ? blk[c].st : init;
+        if (MODE == kSmAdvance && HOT) {
+          const uint32_t st = blk[c].st < d.nStates ? blk[c].st : d.init;
+          s[c] = toHot(st);
+          g[c] = s[c] != 255u ? kNoState : st;
+        } else if (HOT && init == 0x1ffu) {
+          s[c] = 255u;
+          g[c] = d.init;
+        }
       }
     }
 #pragma unroll
     for (int h = 0; h < HALVES; ++h) {
       StreamBook b[CH];
+      uint32_t s0[CH];  // HOT: the half-block's entry state (hot index), for the re-walk
 #pragma unroll
-      for (int c = 0; c < CH; ++c) { b[c].acc = accS[c]; b[c].end = 0; b[c].start = 0; }
+      for (int c = 0; c < CH; ++c) {
+        b[c].acc = HOT ? 0u : accS[c]; b[c].end = 0; b[c].start = 0;
+        s0[c] = s[c];
+      }
       uint4 piece[CH];
 #pragma unroll
       for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[4 * h + 0];
@@ -246,12 +309,37 @@ k_stream(DevDfa d, Batch io) {
       for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[4 * h + 3];
       streamWalk16<MODE, 3>(piece, s, b, mA, mB, firstAccept, init);
       const uint32_t off = r * BLK + h * 64;
+      bool redo[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) redo[c] = HOT && s[c] == 255u;
+      if (HOT && __builtin_amdgcn_ballot_w64(redo[0] || redo[CH - 1])) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          if (redo[c]) {
+            const uint64_t ln = tile * linesPerTile + uint64_t(c) * THREADS + threadIdx.x;
+            uint32_t st = g[c] != kNoState ? g[c] : toGlobal(s0[c]);
+            // lanes past the end of the batch walked a clamped line: nothing of theirs is kept
+            if (ln < io.n) {
+              const SlowBook o = slowHalf<MODE>(d, tab, io.data + ln * lineLen + off, off,
+                                                SlowBook{st, accS[c], endv[c], startv[c]});
+              st = o.st; accS[c] = o.accS; endv[c] = o.endv; startv[c] = o.startv;
+            }
+            s[c] = toHot(st);
+            g[c] = s[c] != 255u ? kNoState : st;
+          }
+        }
+      }
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
-        if (kAcc) {
+        if (HOT && redo[c]) continue;
+        if (kAcc && !HOT) {
           accS[c] = b[c].acc;
           endv[c] = b[c].end ? off + b[c].end : endv[c];
           if (s[c] >= firstAccept) { accS[c] = s[c]; endv[c] = off + 64; }
+        }
+        if (kAcc && HOT) {
+          if (b[c].end) { accS[c] = toGlobal(b[c].acc); endv[c] = off + b[c].end; }
+          if (s[c] >= firstAccept) { accS[c] = toGlobal(s[c]); endv[c] = off + 64; }
         }
         if (kStart) {
           startv[c] = b[c].start ? off + b[c].start - 1 : startv[c];
@@ -268,15 +356,19 @@ k_stream(DevDfa d, Batch io) {
         if (ln < io.n) {
           int32_t rr;
           uint32_t en;
+          const uint32_t sG = !HOT ? s[c] : g[c] != kNoState ? g[c] : toGlobal(s[c]);
           if (kAcc) {
-            rr = endv[c] ? ldsRes[accS[c]] : 0;
+            rr = endv[c] ? (HOT ? d.result[accS[c]] : ldsRes[accS[c]]) : 0;
             en = endv[c];
+          } else if (HOT) {
+            rr = sG >= d.firstAccept ? d.result[sG] : 0;
+            en = lineLen;
           } else {
             rr = s[c] >= firstAccept ? ldsRes[s[c]] : 0;
             en = lineLen;
           }
           io.result[ln] = rr;
-          if (MODE == kSmAdvance) io.state[ln] = s[c];
+          if (MODE == kSmAdvance) io.state[ln] = sG;
           if (io.end) io.end[ln] = rr ? uint64_t(en) : 0;
           if (kStart && io.start) io.start[ln] = rr ? uint64_t(startv[c]) : 0;
         }
@@ -293,6 +385,23 @@ k_stream(DevDfa d, Batch io) {
     issue(A);
     if (q + 1 < Q) walkBlock(B);
   }
+}
+
+// the HOT form of the same launch (512 threads only)
+template <int MODE>
+hipError_t launchStreamHot(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
+                           hipStream_t stream) {
+  constexpr int THREADS = kStreamThreads;
+  const uint64_t linesPerTile = uint64_t(THREADS) * kStreamChains;
+  const uint64_t tiles = (b.n + linesPerTile - 1) / linesPerTile;
+  const uint64_t blocks = tiles < uint64_t(cfg.numCUs) ? tiles : uint64_t(cfg.numCUs);
+  if (b.stride % 128 == 0)
+    hipLaunchKernelGGL((k_stream<MODE, 2, THREADS, true>), dim3(uint32_t(blocks)), dim3(THREADS),
+                       0, stream, d, b);
+  else
+    hipLaunchKernelGGL((k_stream<MODE, 1, THREADS, true>), dim3(uint32_t(blocks)), dim3(THREADS),
+                       0, stream, d, b);
+  return hipGetLastError();
 }
 
 template <int MODE, int THREADS>

@@ -24,7 +24,10 @@ struct DevDfa {
   uint32_t firstAccept;
   uint32_t leaderLen;
   uint32_t deadAbsorbing;
-  uint32_t hotLo, nHot, hotOff;  // REDGPU_TAB_HOT_U16 (dfa_image.h), else 0
+  // REDGPU_TAB_HOT_ROWS (dfa_image.h), else 0: hot states [hotLo, hotLo + nHot), the 64 KB
+  // [hot index][byte] u8 table at table + hot8Off, hot index = s - hotLo + hotShift
+  uint32_t hotLo, nHot, hot8Off, hotShift;
+  uint32_t earlyDeath;           // the visit model sees walks die within 16 bytes
 };
 
 // One batch of lines (device pointers).

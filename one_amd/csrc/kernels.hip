@@ -91,30 +91,34 @@ template <> struct Tab<REDGPU_TAB_GLOBAL_U32> {
 };
 
 // Hot rows (north star: "hot transition rows staged in LDS"): the n_hot most-visited states
-// have a fused [byte] u16 row in LDS - one ds_read_u16 per byte, no class lookup; every other
-// state goes through the class table in HBM/L2.  Hot states are one index range.
-template <> struct Tab<REDGPU_TAB_HOT_U16> {
+// share a 64 KB [hot index][byte] u8 table in LDS - one ds_read_u8 per byte, no class lookup,
+// for every transition that stays inside the hot set; 255 there (the target is not hot) and
+// every cold state go through the class table in HBM/L2.  Hot states are one index range.
+template <> struct Tab<REDGPU_TAB_HOT_ROWS> {
   static constexpr bool kInLds = false;
   const uint16_t *t;
-  const uint16_t *hot;
+  const uint8_t *hot;
   const uint8_t *eq;
-  uint32_t nc, hotLo, nHot;
+  uint32_t nc, hotLo, nHot, shift;
   __device__ Tab(const uint8_t *tab, const uint8_t *equiv, uint32_t nClasses)
       : t(reinterpret_cast<const uint16_t *>(tab)), hot(nullptr), eq(equiv), nc(nClasses),
-        hotLo(0), nHot(0) {}
+        hotLo(0), nHot(0), shift(0) {}
   __device__ __forceinline__ uint32_t next(uint32_t s, uint32_t byte) const {
     const uint32_t hr = s - hotLo;
-    if (hr < nHot) return hot[(hr << 8) | byte];
+    if (hr < nHot) {
+      const uint32_t v = hot[((hr + shift) << 8) | byte];
+      if (v != 255u) return (shift && v == 0) ? 0u : hotLo + v - shift;  // 0: a pure dead end
+    }
     return t[size_t(s) * nc + eq[byte]];
   }
 };
 
 // What a workgroup stages behind its 512 bytes of equivalence map + leader, and the accessor
-// over it.  Whole table for the LDS kinds, the hot rows for REDGPU_TAB_HOT_U16, nothing else.
+// over it.  Whole table for the LDS kinds, the hot rows for REDGPU_TAB_HOT_ROWS, nothing else.
 template <int KIND>
 __host__ __device__ inline size_t ldsTableBytes(const DevDfa &d) {
   if (Tab<KIND>::kInLds) return d.tableBytes;
-  if (KIND == REDGPU_TAB_HOT_U16) return size_t(d.nHot) * 512u;
+  if (KIND == REDGPU_TAB_HOT_ROWS) return 65536u;
   return 0;
 }
 
@@ -127,16 +131,17 @@ __device__ __forceinline__ Tab<KIND> stageTab(const DevDfa &d, uint8_t *lds) {
   const uint32_t n16 = uint32_t(ldsTableBytes<KIND>(d) / 16);
   if (n16) {
     const uint4 *src = reinterpret_cast<const uint4 *>(
-        d.table + (KIND == REDGPU_TAB_HOT_U16 ? d.hotOff : 0u));
+        d.table + (KIND == REDGPU_TAB_HOT_ROWS ? d.hot8Off : 0u));
     uint4 *dst = reinterpret_cast<uint4 *>(ldsTab);
     for (uint32_t i = threadIdx.x; i < n16; i += THREADS) dst[i] = src[i];
   }
   __syncthreads();
   Tab<KIND> tab(Tab<KIND>::kInLds ? ldsTab : d.table, eq, d.nClasses);
-  if constexpr (KIND == REDGPU_TAB_HOT_U16) {
-    tab.hot = reinterpret_cast<const uint16_t *>(ldsTab);
+  if constexpr (KIND == REDGPU_TAB_HOT_ROWS) {
+    tab.hot = ldsTab;
     tab.hotLo = d.hotLo;
     tab.nHot = d.nHot;
+    tab.shift = d.hotShift;
   }
   return tab;
 }
@@ -747,7 +752,7 @@ hipError_t setLds(K kernel, size_t bytes) {
 template <int KIND>
 hipError_t launchGeneric(const DevDfa &d, const Batch &b, int verb, int style, int lead,
                          const LaunchCfg &cfg, hipStream_t stream) {
-  constexpr bool kLds = Tab<KIND>::kInLds || KIND == REDGPU_TAB_HOT_U16;
+  constexpr bool kLds = Tab<KIND>::kInLds || KIND == REDGPU_TAB_HOT_ROWS;
   constexpr int kThreads = kLds ? 1024 : 256;
   const size_t ldsBytes = 512 + ldsTableBytes<KIND>(d);
   hipError_t e = setLds(k_generic<KIND, kThreads>, ldsBytes);
@@ -766,7 +771,7 @@ hipError_t launchGeneric(const DevDfa &d, const Batch &b, int verb, int style, i
 template <int KIND>
 hipError_t launchCollectK(const DevDfa &d, const Batch &b, uint64_t cap, uint64_t *counts,
                           const LaunchCfg &cfg, hipStream_t stream) {
-  constexpr bool kLds = Tab<KIND>::kInLds || KIND == REDGPU_TAB_HOT_U16;
+  constexpr bool kLds = Tab<KIND>::kInLds || KIND == REDGPU_TAB_HOT_ROWS;
   constexpr int kThreads = kLds ? 1024 : 256;
   const size_t ldsBytes = 512 + ldsTableBytes<KIND>(d);
   hipError_t e = setLds(k_collect<KIND, kThreads>, ldsBytes);
@@ -784,7 +789,7 @@ hipError_t launchCollectK(const DevDfa &d, const Batch &b, uint64_t cap, uint64_
 template <int KIND>
 hipError_t launchMatchAllK(const DevDfa &d, const Batch &b, uint64_t cap, uint64_t *counts,
                            int lead, const LaunchCfg &cfg, hipStream_t stream) {
-  constexpr bool kLds = Tab<KIND>::kInLds || KIND == REDGPU_TAB_HOT_U16;
+  constexpr bool kLds = Tab<KIND>::kInLds || KIND == REDGPU_TAB_HOT_ROWS;
   constexpr int kThreads = kLds ? 1024 : 256;
   const size_t ldsBytes = 512 + ldsTableBytes<KIND>(d);
   hipError_t e = setLds(k_matchall<KIND, kThreads>, ldsBytes);
@@ -802,7 +807,7 @@ hipError_t launchMatchAllK(const DevDfa &d, const Batch &b, uint64_t cap, uint64
 template <int KIND>
 hipError_t launchAdvanceK(const DevDfa &d, const Batch &b, uint32_t *state, const LaunchCfg &cfg,
                           hipStream_t stream) {
-  constexpr bool kLds = Tab<KIND>::kInLds || KIND == REDGPU_TAB_HOT_U16;
+  constexpr bool kLds = Tab<KIND>::kInLds || KIND == REDGPU_TAB_HOT_ROWS;
   constexpr int kThreads = kLds ? 1024 : 256;
   const size_t ldsBytes = 512 + ldsTableBytes<KIND>(d);
   hipError_t e = setLds(k_advance<KIND, kThreads>, ldsBytes);
@@ -863,6 +868,12 @@ hipError_t launchFixedS(int style, const DevDfa &d, const Batch &b, uint32_t sta
 
 } // namespace
 
+// REDGPU_TAB_HOT_ROWS DFAs whose hot set the streaming kernel can index with one byte
+static bool hotStreamEligible(const DevDfa &d) {
+  return d.tableKind == REDGPU_TAB_HOT_ROWS && d.nHot > 0 && d.hot8Off != 0 &&
+         d.deadAbsorbing && !d.earlyDeath;
+}
+
 bool fastPathEligible(const DevDfa &d) {
   return d.tableKind == REDGPU_TAB_LDS_FUSED_U8 && d.deadAbsorbing &&
          size_t(d.tableBytes) + size_t(d.nStates) * 4 <= 150 * 1024;
@@ -880,8 +891,8 @@ hipError_t launchCollect(const DevDfa &d, const Batch &b, uint64_t cap, uint64_t
     return launchCollectK<REDGPU_TAB_LDS_CLASS_U16>(d, b, cap, counts, cfg, stream);
   case REDGPU_TAB_GLOBAL_U16:
     return launchCollectK<REDGPU_TAB_GLOBAL_U16>(d, b, cap, counts, cfg, stream);
-  case REDGPU_TAB_HOT_U16:
-    return launchCollectK<REDGPU_TAB_HOT_U16>(d, b, cap, counts, cfg, stream);
+  case REDGPU_TAB_HOT_ROWS:
+    return launchCollectK<REDGPU_TAB_HOT_ROWS>(d, b, cap, counts, cfg, stream);
   default:
     return launchCollectK<REDGPU_TAB_GLOBAL_U32>(d, b, cap, counts, cfg, stream);
   }
@@ -893,7 +904,7 @@ hipError_t launchCollect(const DevDfa &d, const Batch &b, uint64_t cap, uint64_t
   case REDGPU_TAB_LDS_FUSED_U16: return CALL(REDGPU_TAB_LDS_FUSED_U16);                   \
   case REDGPU_TAB_LDS_CLASS_U16: return CALL(REDGPU_TAB_LDS_CLASS_U16);                   \
   case REDGPU_TAB_GLOBAL_U16: return CALL(REDGPU_TAB_GLOBAL_U16);                         \
-  case REDGPU_TAB_HOT_U16: return CALL(REDGPU_TAB_HOT_U16);                               \
+  case REDGPU_TAB_HOT_ROWS: return CALL(REDGPU_TAB_HOT_ROWS);                               \
   default: return CALL(REDGPU_TAB_GLOBAL_U32);                                            \
   }
 
@@ -921,6 +932,16 @@ hipError_t launchAdvance(const DevDfa &d, const Batch &b, uint32_t *state, const
     sb.start = nullptr;
     sb.end = nullptr;
     return launchStreamT<kSmAdvance>(d, sb, cfg, stream);
+  }
+  if (!cfg.forceGeneric && hotStreamEligible(d) && !b.offsets && b.stride >= 64 &&
+      b.stride % 64 == 0 && b.stride < (1ull << 31) &&
+      (reinterpret_cast<uintptr_t>(b.data) % 16) == 0) {
+    *kernelName = "k_stream<advance,hot>";
+    Batch sb = b;
+    sb.state = state;
+    sb.start = nullptr;
+    sb.end = nullptr;
+    return launchStreamHot<kSmAdvance>(d, sb, cfg, stream);
   }
 #define AD_CALL(K) launchAdvanceK<K>(d, b, state, cfg, stream)
   REDGPU_KIND_SWITCH(AD_CALL)
@@ -955,6 +976,33 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
     } else {
       if (sb.start) { *kernelName = "k_stream<full,start>"; e = launchStreamT<kSmFullStart>(d, sb, cfg, stream); }
       else { *kernelName = "k_stream<full>"; e = launchStreamT<kSmFull>(d, sb, cfg, stream); }
+    }
+    if (e != hipSuccess) return e;
+    if (lead) {
+      hipLaunchKernelGGL(k_leader_filter, dim3(uint32_t(cfg.numCUs) * 8), dim3(256), 0, stream,
+                         d, b);
+      return hipGetLastError();
+    }
+    return hipSuccess;
+  }
+  // The same streaming walk for DFAs too big for LDS: hot rows as a one-byte-indexed table,
+  // cold excursions re-walked per 64-byte half-block (k_stream.h, HOT).
+  const bool hotStreamOk = !cfg.forceGeneric && hotStreamEligible(d) && !b.offsets &&
+                           (verb == kCheck || verb == kMatch) &&
+                           (style == kStyLast || style == kStyFull) && b.stride >= 64 &&
+                           b.stride % 64 == 0 && b.stride < (1ull << 31) &&
+                           (reinterpret_cast<uintptr_t>(b.data) % 16) == 0 &&
+                           !(lead && verb == kCheck);
+  if (hotStreamOk) {
+    hipError_t e;
+    Batch sb = b;
+    if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
+    if (style == kStyLast) {
+      if (sb.start) { *kernelName = "k_stream<last,start,end,hot>"; e = launchStreamHot<kSmLastStartEnd>(d, sb, cfg, stream); }
+      else { *kernelName = "k_stream<last,end,hot>"; e = launchStreamHot<kSmLastEnd>(d, sb, cfg, stream); }
+    } else {
+      if (sb.start) { *kernelName = "k_stream<full,start,hot>"; e = launchStreamHot<kSmFullStart>(d, sb, cfg, stream); }
+      else { *kernelName = "k_stream<full,hot>"; e = launchStreamHot<kSmFull>(d, sb, cfg, stream); }
     }
     if (e != hipSuccess) return e;
     if (lead) {
@@ -1019,8 +1067,8 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
     return launchGeneric<REDGPU_TAB_LDS_CLASS_U16>(d, b, verb, style, lead, cfg, stream);
   case REDGPU_TAB_GLOBAL_U16:
     return launchGeneric<REDGPU_TAB_GLOBAL_U16>(d, b, verb, style, lead, cfg, stream);
-  case REDGPU_TAB_HOT_U16:
-    return launchGeneric<REDGPU_TAB_HOT_U16>(d, b, verb, style, lead, cfg, stream);
+  case REDGPU_TAB_HOT_ROWS:
+    return launchGeneric<REDGPU_TAB_HOT_ROWS>(d, b, verb, style, lead, cfg, stream);
   default:
     return launchGeneric<REDGPU_TAB_GLOBAL_U32>(d, b, verb, style, lead, cfg, stream);
   }

@@ -276,7 +276,9 @@ int redgpu_dfa_create(const void *reda, size_t len, const redgpu_opts *opts, red
   d.deadAbsorbing = img.deadAbsorbing ? 1 : 0;
   d.hotLo = img.hotLo;
   d.nHot = img.nHot;
-  d.hotOff = img.hotOff;
+  d.hot8Off = img.hot8Off;
+  d.hotShift = img.hotShift;
+  d.earlyDeath = img.earlyDeath ? 1 : 0;
   *out = h;
   return REDGPU_OK;
 }
@@ -312,7 +314,7 @@ int redgpu_dfa_info(const redgpu_dfa *h, redgpu_info *out) {
   out->n_hot = img.nHot;
   out->hot_lo = img.hotLo;
   out->hot_coverage_ppm = img.hotCoveragePpm;
-  out->reserved = 0;
+  out->early_death = img.earlyDeath ? 1 : 0;
   return REDGPU_OK;
 }
 

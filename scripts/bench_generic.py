@@ -44,6 +44,16 @@ timeit(lambda: one_amd.match_batch(exe7, d6, 4, 0, stride=L6, n=n6), n6 * L6, "U
 n8, L8 = 1 << 20, 256
 t8 = W.fixed_lines(n8, L8, 8, alphabet=True, plant=W.URI_V6_PLANT, plant_every=8, plant_at=32)
 d8 = torch.from_numpy(t8).cuda()
-timeit(lambda: one_amd.match_batch(exe7, d8, 4, 0, stride=L8, n=n8), n8 * L8, "URI-V6 2^20 x 256 B text, URL planted every 8th line", it=3)
+timeit(lambda: one_amd.match_batch(exe7, d8, 4, 0, stride=L8, n=n8), n8 * L8, "URI-V6 2^20 x 256 B text, IPv6 URL planted every 8th line", it=3)
+t9 = W.fixed_lines(n8, L8, 9, alphabet=True, plant=W.URI_PLANT, plant_every=8, plant_at=32)
+d9 = torch.from_numpy(t9).cuda()
+timeit(lambda: one_amd.match_batch(exe7, d9, 4, 0, stride=L8, n=n8), n8 * L8, "URI-V6 2^20 x 256 B text, https://name URL every 8th line", it=3)
+t10 = W.fixed_lines(n8, L8, 10, alphabet=True)
+d10 = torch.from_numpy(t10).cuda()
+timeit(lambda: one_amd.match_batch(exe7, d10, 4, 0, stride=L8, n=n8), n8 * L8, "URI-V6 2^20 x 256 B text, no URL", it=3)
+exe7g = one_amd.Executable(load_dfa("uri_v6"), force_generic=True)
+timeit(lambda: one_amd.match_batch(exe7g, d9, 4, 0, stride=L8, n=n8), n8 * L8, "  same (https URL), generic kernel + hot rows", it=3)
+exe7gg = one_amd.Executable(load_dfa("uri_v6"), force_generic=True, force_global=True)
+timeit(lambda: one_amd.match_batch(exe7gg, d9, 4, 0, stride=L8, n=n8), n8 * L8, "  same (https URL), generic kernel, table in L2 only", it=3)
 exe9 = one_amd.Executable(load_dfa("log100"))
 timeit(lambda: one_amd.match_batch(exe9, d8, 4, 0, stride=L8, n=n8), n8 * L8, "LOG-100 match<Last,false> same text (dies early)", it=3)

@@ -160,13 +160,13 @@ def test_random_dfas_vs_oracle(seed):
 
 @pytest.mark.parametrize("rows", [0, 8, 40, 200])
 def test_hot_row_tables_vs_oracle(rows):
-    """REDGPU_TAB_HOT_U16: hot states' fused rows in LDS, the rest in the class table in L2.
+    """REDGPU_TAB_HOT_ROWS: the hot states' [hot index][byte] u8 table in LDS, the rest in the class table in L2.
     A random DFA whose walk keeps crossing between hot and cold states (the LDS budget is set
     so that only `rows` rows fit; 0 = default budget), every verb and style, against the
     oracle; then the two reference-compiled big DFAs at several budgets."""
     blob = random_dfa(2500, 48, 77, dead_frac=0.01, accept_frac=0.2)  # 240 KB class table
     # a dense random DFA has no locality: force_hot keeps the hot rows anyway
-    exe = one_amd.Executable(blob, force_hot=True, lds_table_max=(rows or 100) * 512)
+    exe = one_amd.Executable(blob, force_hot=True, lds_table_max=(rows or 100) * 256)
     cpu = O.CpuOracle(blob)
     assert exe.info["table_kind"] == 6 and exe.info["n_hot"] == (rows or 100)
     rng = np.random.default_rng(rows)
@@ -193,13 +193,74 @@ def test_hot_row_tables_vs_oracle(rows):
     assert np.array_equal(got[0], exp[0])
     for name in ("log100", "uri_v6"):
         vec = load_vectors(name)
-        exe = one_amd.Executable(load_dfa(name), **({"lds_table_max": rows * 512} if rows else {}))
+        exe = one_amd.Executable(load_dfa(name), **({"lds_table_max": rows * 256} if rows else {}))
         assert exe.info["table_kind"] == 6
         for lead in (0, 1):
             r, s, e = one_amd.match_batch(exe, vec["data"], 4, lead, offsets=vec["offsets"])
             key = "match_4_%d_" % lead
             assert np.array_equal(r, vec[key + "res"]) and np.array_equal(s, vec[key + "start"])
             assert np.array_equal(e, vec[key + "end"])
+
+
+@pytest.mark.parametrize("case", ["uri_v6_random", "uri_v6_text", "log100_text", "random_cold",
+                                  "random_cold_dead"])
+def test_hot_row_streaming_kernel_vs_oracle(case):
+    """k_stream<.., hot>: fixed-stride lines over a DFA too big for LDS.  All-hot walks (random
+    bytes over a real regex), walks with cold excursions (planted URLs / log signatures), and a
+    dense random DFA with 40 forced hot rows where nearly every half-block is re-walked by the
+    slow path; every mode of the kernel, 64- and 128-byte blocks, a ragged last tile."""
+    if case.startswith("random_cold"):
+        # "_dead": a few transitions lead to the (absorbing) error state: hot index 0
+        blob = random_dfa(2500, 48, 78, dead_frac=0.004 if case.endswith("dead") else 0.0,
+                          accept_frac=0.2)
+        exe = one_amd.Executable(blob, force_hot=True, lds_table_max=40 * 256)
+        mk = lambda n, L, seed: W.fixed_lines(n, L, seed, alphabet=False)
+    else:
+        name = "log100" if case.startswith("log100") else "uri_v6"
+        blob = load_dfa(name)
+        exe = one_amd.Executable(blob)
+        if case == "uri_v6_random":
+            mk = lambda n, L, seed: W.fixed_lines(n, L, seed, alphabet=False)
+        elif case == "uri_v6_text":
+            mk = lambda n, L, seed: W.fixed_lines(n, L, seed, alphabet=True, plant=W.URI_V6_PLANT,
+                                                  plant_every=3, plant_at=L // 2 - 9)
+        else:
+            heads = W.log100_heads()
+            def mk(n, L, seed):
+                a = W.fixed_lines(n, L, seed, alphabet=True).reshape(n, L)
+                for i in range(0, n, 2):          # every other line starts with a signature
+                    h = np.frombuffer(heads[i % len(heads)], dtype=np.uint8)[:L]
+                    a[i, :len(h)] = h
+                return a.reshape(-1)
+    cpu = O.CpuOracle(blob)
+    assert exe.info["table_kind"] == 6 and exe.info["n_hot"] <= 254
+    anchored = bool(exe.info["early_death"])   # such DFAs keep the early-exit kernels
+    for n, L in ((3001, 64), (1500, 128), (700, 192), (257, 4096)):
+        data = mk(n, L, 100 + L)
+        for sty in (4, 5):
+            er, es, ee = cpu.batch("match", sty, 0, data, stride=L, n=n, threads=8)
+            r, s, e = one_amd.match_batch(exe, data, sty, 0, stride=L, n=n)
+            assert anchored or (one_amd.last_kernel().startswith("k_stream<") and
+                                "hot" in one_amd.last_kernel()), one_amd.last_kernel()
+            assert np.array_equal(r, er), (case, n, L, sty)
+            assert np.array_equal(s, es) and np.array_equal(e, ee), (case, n, L, sty)
+            r, _, e = one_amd.match_batch(exe, data, sty, 1, stride=L, n=n, want_start=False)
+            assert np.array_equal(r, er) and np.array_equal(e, ee)
+            assert np.array_equal(one_amd.check_batch(exe, data, sty, 0, stride=L, n=n),
+                                  cpu.batch("check", sty, 0, data, stride=L, n=n, threads=8)[0])
+        # StatefulMatcher chunks through the same kernel: two chunks of L/2 when that is whole
+        # 64-byte blocks, else one chunk
+        state = np.full(n, one_amd.STATE_INITIAL, dtype=np.uint32)
+        if L % 128 == 0:
+            a = data.reshape(n, L)
+            for half in (a[:, :L // 2], a[:, L // 2:]):
+                res = one_amd.advance_batch(exe, np.ascontiguousarray(half).reshape(-1), state,
+                                            stride=L // 2, n=n)
+        else:
+            res = one_amd.advance_batch(exe, data, state, stride=L, n=n)
+        assert anchored or one_amd.last_kernel() == "k_stream<advance,hot>"
+        ostate = np.full(n, O.STATE_INITIAL, dtype=np.uint32)
+        assert np.array_equal(res, cpu.advance_batch(data, ostate, stride=L, n=n))
 
 
 def test_edge_cases():

@@ -118,6 +118,19 @@ void redgpu_dfa_destroy(redgpu_dfa *dfa);
 /* Replaces the Executable accessors (include/Executable.h:52-60). */
 int redgpu_dfa_info(const redgpu_dfa *dfa, redgpu_info *out);
 
+/* No counterpart in the reference - there the table lives in CPU caches, which adapt to the
+ * input on their own.  For a DFA placed as REDGPU_TAB_HOT_ROWS this is the explicit version:
+ * walks a SAMPLE of real input (anchored, as match<styLast,false> does: include/Matcher.h:413-495)
+ * counting visits per state, then re-ranks the hot rows by those counts and rebuilds and
+ * re-uploads the image.  Results never change, only which transitions are served from LDS.
+ * Not re-entrant: call it before the handle is shared between threads; it waits for all work
+ * queued on the device.  State tokens of redgpu_advance_batch taken before the call are
+ * invalid after it.  Other placements: validates its arguments and does nothing. */
+int redgpu_dfa_tune(redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,
+                    uint64_t stride, uint64_t n);
+int redgpu_dfa_tune_dev(redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,
+                        uint64_t stride, uint64_t n, void *stream);
+
 /* Replaces Executable::serialized() (include/Executable.h:50): the handle's own copy. */
 int redgpu_dfa_serialized(const redgpu_dfa *dfa, const void **reda, size_t *len);
 

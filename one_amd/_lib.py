@@ -114,6 +114,10 @@ def lib() -> C.CDLL:
         l.redgpu_advance_batch.argtypes = [vp, vp, vp, u64, u64, vp, vp]
         l.redgpu_advance_batch_dev.restype = C.c_int
         l.redgpu_advance_batch_dev.argtypes = [vp, vp, vp, u64, u64, vp, vp, vp]
+        l.redgpu_dfa_tune.restype = C.c_int
+        l.redgpu_dfa_tune.argtypes = [vp, vp, vp, u64, u64]
+        l.redgpu_dfa_tune_dev.restype = C.c_int
+        l.redgpu_dfa_tune_dev.argtypes = [vp, vp, vp, u64, u64, vp]
         _lib = l
     return _lib
 

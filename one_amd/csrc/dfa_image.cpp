@@ -64,7 +64,8 @@ const char *checkHeader(const void *ptr, size_t len) {
 }
 
 std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool forceGlobal,
-                       DfaImage &img, int &errCode, bool forceHot) {
+                       DfaImage &img, int &errCode, bool forceHot,
+                       const std::vector<double> *measured) {
   errCode = REDGPU_EAPI;
   if (!reda || len == 0)
     return "serialized dfa is empty";
@@ -214,6 +215,14 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
       if (step == 15) img.earlyDeath = died > 0.5;
       p.swap(q);
     }
+    if (measured && measured->size() == stateCnt) {
+      // observed visits decide; the model (scaled far below one observed visit) breaks ties
+      double msum = 0.0, vsum = 0.0;
+      for (uint32_t s : reach) { msum += (*measured)[s]; vsum += visits[s]; }
+      if (msum > 0.0)
+        for (uint32_t s : reach)
+          visits[s] = (*measured)[s] / msum + 1e-9 * (vsum > 0.0 ? visits[s] / vsum : 0.0);
+    }
     std::vector<uint32_t> cand;
     double total = 0.0;
     for (uint32_t s : reach)
@@ -274,6 +283,7 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
   std::vector<uint32_t> newId(stateCnt, 0xffffffffu);
   for (uint32_t i = 0; i < img.nStates; ++i)
     newId[order[i]] = i;
+  img.rawOf = order;
   img.init = newId[rawInit];
   img.leaderNext = newId[rawLead];
 

@@ -41,6 +41,7 @@ struct DfaImage {
   bool     deadAbsorbing = true;  // every pure dead end self-loops on every class
   std::vector<int32_t>  result;   // [nStates]
   std::vector<uint32_t> next;     // [nStates][nClasses], device indices
+  std::vector<uint32_t> rawOf;    // [nStates] device index -> state id in the blob
   // table chosen for the device
   uint32_t tableKind = 0;         // REDGPU_TAB_*
   std::vector<uint8_t> table;     // packed bytes of that table
@@ -66,7 +67,11 @@ uint32_t calcChecksum(const void *ptr, size_t len);
 
 // Parses + bounds-checks + renumbers.  Returns "" on success, else the error message
 // (code: REDGPU_EAPI for a bad blob, REDGPU_ELIMIT for capacity).
+// `measured` (optional, one entry per state of the BLOB, stateCnt_ of them): visit counts
+// observed on real input (redgpu_dfa_tune); they then rank the hot rows, the model only
+// breaking ties.
 std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool forceGlobal,
-                       DfaImage &img, int &errCode, bool forceHot = false);
+                       DfaImage &img, int &errCode, bool forceHot = false,
+                       const std::vector<double> *measured = nullptr);
 
 } // namespace redgpu

@@ -67,6 +67,11 @@ hipError_t launchMatchAll(const DevDfa &dfa, const Batch &b, uint64_t cap, uint6
 hipError_t launchAdvance(const DevDfa &dfa, const Batch &b, uint32_t *state, const LaunchCfg &cfg,
                          hipStream_t stream, const char **kernelName);
 
+// redgpu_dfa_tune's profiling pass: hist[device state] += 1 per byte the anchored walk of
+// match<styLast,false> consumes over the sample (hist zeroed by the caller).
+hipError_t launchVisits(const DevDfa &dfa, const Batch &b, uint32_t *hist, const LaunchCfg &cfg,
+                        hipStream_t stream);
+
 // True when the specialised fixed-stride kernels can run this DFA at all.
 bool fastPathEligible(const DevDfa &dfa);
 

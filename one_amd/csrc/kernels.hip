@@ -742,6 +742,35 @@ k_advance(DevDfa d, Batch b, uint32_t *state) {
   }
 }
 
+// Visit histogram for redgpu_dfa_tune: the anchored walk of match<styLast,false> over every
+// line of a SAMPLE, hist[state] += 1 per byte consumed.  A profiling pass, not a hot path:
+// plain global atomics.
+template <int KIND, int kThreads>
+__global__ void __launch_bounds__(kThreads)
+k_visits(DevDfa d, Batch b, uint32_t *hist) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const Tab<KIND> tab = stageTab<KIND, kThreads>(d, lds);
+  const uint64_t step = uint64_t(gridDim.x) * kThreads;
+  for (uint64_t line = uint64_t(blockIdx.x) * kThreads + threadIdx.x; line < b.n; line += step) {
+    const uint8_t *p;
+    uint64_t n;
+    if (b.offsets) {
+      const uint64_t o = b.offsets[line];
+      p = b.data + o;
+      n = b.offsets[line + 1] - o;
+    } else {
+      p = b.data + line * b.stride;
+      n = b.stride;
+    }
+    uint32_t s = d.init;
+    walkBytes(p, 0, n, [&](uint32_t byte, uint64_t) {
+      s = tab.next(s, byte);
+      atomicAdd(&hist[s], 1u);
+      return s >= d.nPureDead;
+    });
+  }
+}
+
 template <class K>
 hipError_t setLds(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return hipSuccess;
@@ -801,6 +830,24 @@ hipError_t launchMatchAllK(const DevDfa &d, const Batch &b, uint64_t cap, uint64
   if (blocks == 0) blocks = 1;
   hipLaunchKernelGGL((k_matchall<KIND, kThreads>), dim3(uint32_t(blocks)), dim3(kThreads),
                      ldsBytes, stream, d, b, cap, counts, lead);
+  return hipGetLastError();
+}
+
+template <int KIND>
+hipError_t launchVisitsK(const DevDfa &d, const Batch &b, uint32_t *hist, const LaunchCfg &cfg,
+                         hipStream_t stream) {
+  constexpr bool kLds = Tab<KIND>::kInLds || KIND == REDGPU_TAB_HOT_ROWS;
+  constexpr int kThreads = kLds ? 1024 : 256;
+  const size_t ldsBytes = 512 + ldsTableBytes<KIND>(d);
+  hipError_t e = setLds(k_visits<KIND, kThreads>, ldsBytes);
+  if (e != hipSuccess) return e;
+  uint64_t blocks = (b.n + kThreads - 1) / kThreads;
+  const uint64_t perCu = kLds ? (ldsBytes <= 80 * 1024 ? 2 : 1) : 8;
+  const uint64_t capBlocks = uint64_t(cfg.numCUs) * perCu;
+  if (blocks > capBlocks) blocks = capBlocks;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL((k_visits<KIND, kThreads>), dim3(uint32_t(blocks)), dim3(kThreads), ldsBytes,
+                     stream, d, b, hist);
   return hipGetLastError();
 }
 
@@ -915,6 +962,14 @@ hipError_t launchMatchAll(const DevDfa &d, const Batch &b, uint64_t cap, uint64_
 #define MA_CALL(K) launchMatchAllK<K>(d, b, cap, counts, lead, cfg, stream)
   REDGPU_KIND_SWITCH(MA_CALL)
 #undef MA_CALL
+}
+
+hipError_t launchVisits(const DevDfa &d, const Batch &b, uint32_t *hist, const LaunchCfg &cfg,
+                        hipStream_t stream) {
+  if (b.n == 0) return hipSuccess;
+#define VI_CALL(K) launchVisitsK<K>(d, b, hist, cfg, stream)
+  REDGPU_KIND_SWITCH(VI_CALL)
+#undef VI_CALL
 }
 
 hipError_t launchAdvance(const DevDfa &d, const Batch &b, uint32_t *state, const LaunchCfg &cfg,

@@ -23,6 +23,7 @@ struct redgpu_dfa {
   int device = REDGPU_DEVICE_NONE;
   int numCUs = 0;
   uint32_t flags = 0;
+  uint32_t ldsTableMax = 0;
   // device allocations
   void *dTable = nullptr;
   void *dResult = nullptr;
@@ -182,6 +183,59 @@ int collectDev(const redgpu_dfa *dfa, int listVerb, const uint8_t *data, const u
   return REDGPU_OK;
 }
 
+// (Re)uploads h->img to h->device; frees what was there before.  Caller holds the device scope.
+void freeDeviceImage(redgpu_dfa *h) {
+  if (h->dTable) (void)hipFree(h->dTable);
+  if (h->dResult) (void)hipFree(h->dResult);
+  if (h->dEquivLeader) (void)hipFree(h->dEquivLeader);
+  h->dTable = h->dResult = h->dEquivLeader = nullptr;
+}
+
+int uploadImage(redgpu_dfa *h) {
+  freeDeviceImage(h);
+  const DfaImage &img = h->img;
+  uint8_t eqLead[512];
+  std::memcpy(eqLead, img.equiv, 256);
+  std::memcpy(eqLead + 256, img.leader, 256);
+  const size_t tabBytes = (img.table.size() + 15) & ~size_t(15);
+  hipError_t e;
+  auto bail = [&](hipError_t er, const char *what) { return failHip(er, what); };
+  if ((e = hipMalloc(&h->dTable, tabBytes + 16)) != hipSuccess) return bail(e, "hipMalloc table");
+  if ((e = hipMalloc(&h->dResult, img.nStates * sizeof(int32_t) + 16)) != hipSuccess)
+    return bail(e, "hipMalloc result");
+  if ((e = hipMalloc(&h->dEquivLeader, 512)) != hipSuccess) return bail(e, "hipMalloc equiv");
+  if ((e = hipMemset(h->dTable, 0, tabBytes + 16)) != hipSuccess) return bail(e, "hipMemset");
+  if ((e = hipMemcpy(h->dTable, img.table.data(), img.table.size(), hipMemcpyHostToDevice)) !=
+      hipSuccess)
+    return bail(e, "upload table");
+  if ((e = hipMemcpy(h->dResult, img.result.data(), img.nStates * sizeof(int32_t),
+                     hipMemcpyHostToDevice)) != hipSuccess)
+    return bail(e, "upload result");
+  if ((e = hipMemcpy(h->dEquivLeader, eqLead, 512, hipMemcpyHostToDevice)) != hipSuccess)
+    return bail(e, "upload equiv");
+
+  DevDfa &d = h->dev;
+  d.table = static_cast<const uint8_t *>(h->dTable);
+  d.result = static_cast<const int32_t *>(h->dResult);
+  d.equivLeader = static_cast<const uint8_t *>(h->dEquivLeader);
+  d.tableKind = img.tableKind;
+  d.tableBytes = uint32_t(tabBytes);
+  d.nStates = img.nStates;
+  d.nClasses = img.nClasses;
+  d.init = img.init;
+  d.leaderNext = img.leaderNext;
+  d.nPureDead = img.nPureDead;
+  d.firstAccept = img.firstAccept;
+  d.leaderLen = img.leaderLen;
+  d.deadAbsorbing = img.deadAbsorbing ? 1 : 0;
+  d.hotLo = img.hotLo;
+  d.nHot = img.nHot;
+  d.hot8Off = img.hot8Off;
+  d.hotShift = img.hotShift;
+  d.earlyDeath = img.earlyDeath ? 1 : 0;
+  return REDGPU_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -217,6 +271,7 @@ int redgpu_dfa_create(const void *reda, size_t len, const redgpu_opts *opts, red
   }
   h->blob.assign(static_cast<const uint8_t *>(reda), static_cast<const uint8_t *>(reda) + len);
   h->flags = o.flags;
+  h->ldsTableMax = o.lds_table_max;
   if (o.device == REDGPU_DEVICE_NONE) {
     h->device = REDGPU_DEVICE_NONE;
     *out = h;
@@ -236,49 +291,10 @@ int redgpu_dfa_create(const void *reda, size_t len, const redgpu_opts *opts, red
   h->device = dev;
   h->numCUs = prop.multiProcessorCount;
 
-  const DfaImage &img = h->img;
-  uint8_t eqLead[512];
-  std::memcpy(eqLead, img.equiv, 256);
-  std::memcpy(eqLead + 256, img.leader, 256);
-  const size_t tabBytes = (img.table.size() + 15) & ~size_t(15);
-  auto bail = [&](hipError_t er, const char *what) {
-    int rc = failHip(er, what);
+  if (int rc = uploadImage(h)) {
     redgpu_dfa_destroy(h);
     return rc;
-  };
-  if ((e = hipMalloc(&h->dTable, tabBytes + 16)) != hipSuccess) return bail(e, "hipMalloc table");
-  if ((e = hipMalloc(&h->dResult, img.nStates * sizeof(int32_t) + 16)) != hipSuccess)
-    return bail(e, "hipMalloc result");
-  if ((e = hipMalloc(&h->dEquivLeader, 512)) != hipSuccess) return bail(e, "hipMalloc equiv");
-  if ((e = hipMemset(h->dTable, 0, tabBytes + 16)) != hipSuccess) return bail(e, "hipMemset");
-  if ((e = hipMemcpy(h->dTable, img.table.data(), img.table.size(), hipMemcpyHostToDevice)) !=
-      hipSuccess)
-    return bail(e, "upload table");
-  if ((e = hipMemcpy(h->dResult, img.result.data(), img.nStates * sizeof(int32_t),
-                     hipMemcpyHostToDevice)) != hipSuccess)
-    return bail(e, "upload result");
-  if ((e = hipMemcpy(h->dEquivLeader, eqLead, 512, hipMemcpyHostToDevice)) != hipSuccess)
-    return bail(e, "upload equiv");
-
-  DevDfa &d = h->dev;
-  d.table = static_cast<const uint8_t *>(h->dTable);
-  d.result = static_cast<const int32_t *>(h->dResult);
-  d.equivLeader = static_cast<const uint8_t *>(h->dEquivLeader);
-  d.tableKind = img.tableKind;
-  d.tableBytes = uint32_t(tabBytes);
-  d.nStates = img.nStates;
-  d.nClasses = img.nClasses;
-  d.init = img.init;
-  d.leaderNext = img.leaderNext;
-  d.nPureDead = img.nPureDead;
-  d.firstAccept = img.firstAccept;
-  d.leaderLen = img.leaderLen;
-  d.deadAbsorbing = img.deadAbsorbing ? 1 : 0;
-  d.hotLo = img.hotLo;
-  d.nHot = img.nHot;
-  d.hot8Off = img.hot8Off;
-  d.hotShift = img.hotShift;
-  d.earlyDeath = img.earlyDeath ? 1 : 0;
+  }
   *out = h;
   return REDGPU_OK;
 }
@@ -287,9 +303,7 @@ void redgpu_dfa_destroy(redgpu_dfa *h) {
   if (!h) return;
   if (h->device >= 0) {
     DeviceScope scope(h->device);
-    if (h->dTable) (void)hipFree(h->dTable);
-    if (h->dResult) (void)hipFree(h->dResult);
-    if (h->dEquivLeader) (void)hipFree(h->dEquivLeader);
+    freeDeviceImage(h);
   }
   delete h;
 }
@@ -435,6 +449,90 @@ static int listHost(const redgpu_dfa *dfa, int listVerb, const uint8_t *data,
 #undef CH_TRY
   cleanup();
   return REDGPU_OK;
+}
+
+int redgpu_dfa_tune_dev(redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,
+                        uint64_t stride, uint64_t n, void *stream) {
+  if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
+  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (n == 0) return REDGPU_OK;
+  if (!data && (offsets || stride)) return fail(REDGPU_EAPI, "null data buffer");
+  DeviceScope scope(dfa->device);
+  if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  // a table that is in LDS whole has nothing to re-rank
+  if (dfa->img.tableKind == REDGPU_TAB_LDS_FUSED_U8 || dfa->img.tableKind == REDGPU_TAB_LDS_FUSED_U16 ||
+      dfa->img.tableKind == REDGPU_TAB_LDS_CLASS_U16)
+    return REDGPU_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const uint32_t nStates = dfa->img.nStates;
+  uint32_t *dHist = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dHist), size_t(nStates) * 4), "hipMalloc histogram");
+  auto done = [&](int rc) { (void)hipFree(dHist); return rc; };
+  hipError_t e = hipMemsetAsync(dHist, 0, size_t(nStates) * 4, s);
+  if (e != hipSuccess) return done(failHip(e, "hipMemsetAsync"));
+  Batch b{data, offsets, stride, n, nullptr, nullptr, nullptr};
+  LaunchCfg cfg{dfa->numCUs, 0};
+  e = launchVisits(dfa->dev, b, dHist, cfg, s);
+  tlsKernel = "k_visits";
+  if (e != hipSuccess) return done(failHip(e, "kernel launch"));
+  std::vector<uint32_t> hist(nStates);
+  e = hipMemcpyAsync(hist.data(), dHist, size_t(nStates) * 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return done(failHip(e, "histogram copy"));
+  (void)hipFree(dHist);
+  dHist = nullptr;
+
+  // device index -> blob state id, then the same builder with the observed visits
+  std::vector<double> measured(dfa->img.statesTotal, 0.0);
+  for (uint32_t i = 0; i < nStates; ++i) measured[dfa->img.rawOf[i]] = double(hist[i]);
+  DfaImage img;
+  int code = REDGPU_OK;
+  std::string err = buildImage(dfa->blob.data(), dfa->blob.size(), dfa->ldsTableMax,
+                               (dfa->flags & REDGPU_F_FORCE_GLOBAL) != 0, img, code,
+                               (dfa->flags & REDGPU_F_FORCE_HOT) != 0, &measured);
+  if (!err.empty()) return fail(code, err);
+  // all work queued on the device so far may still read the old tables
+  e = hipDeviceSynchronize();
+  if (e != hipSuccess) return failHip(e, "hipDeviceSynchronize");
+  dfa->img = std::move(img);
+  return uploadImage(dfa);
+}
+
+int redgpu_dfa_tune(redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets, uint64_t stride,
+                    uint64_t n) {
+  if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
+  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (n == 0) return REDGPU_OK;
+  const uint64_t total = offsets ? offsets[n] : stride * n;
+  if (offsets) {
+    for (uint64_t i = 0; i < n; ++i)
+      if (offsets[i] > offsets[i + 1]) return fail(REDGPU_EAPI, "offsets not monotonic");
+  }
+  if (total && !data) return fail(REDGPU_EAPI, "null data buffer");
+  DeviceScope scope(dfa->device);
+  if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  uint8_t *dData = nullptr;
+  uint64_t *dOff = nullptr;
+  auto cleanup = [&]() {
+    if (dData) (void)hipFree(dData);
+    if (dOff) (void)hipFree(dOff);
+  };
+  int rc = REDGPU_OK;
+#define TU_TRY(expr, what)                                                    \
+  do {                                                                        \
+    hipError_t e_ = (expr);                                                   \
+    if (e_ != hipSuccess) { rc = failHip(e_, what); cleanup(); return rc; }   \
+  } while (0)
+  TU_TRY(hipMalloc(reinterpret_cast<void **>(&dData), total + 16), "hipMalloc data");
+  if (offsets) {
+    TU_TRY(hipMalloc(reinterpret_cast<void **>(&dOff), (n + 1) * 8), "hipMalloc offsets");
+    TU_TRY(hipMemcpy(dOff, offsets, (n + 1) * 8, hipMemcpyHostToDevice), "copy offsets");
+  }
+  if (total) TU_TRY(hipMemcpy(dData, data, total, hipMemcpyHostToDevice), "copy data");
+#undef TU_TRY
+  rc = redgpu_dfa_tune_dev(dfa, dData, dOff, stride, n, nullptr);
+  cleanup();
+  return rc;
 }
 
 int redgpu_advance_batch_dev(const redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,

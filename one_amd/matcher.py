@@ -107,6 +107,31 @@ class Executable:
         _check(_lib.lib().redgpu_dfa_info(self._h, C.byref(i)))
         return {k: getattr(i, k) for k, _ in _lib.Info._fields_}
 
+    def tune(self, data, *, offsets=None, stride=0, n=None) -> dict:
+        """redgpu_dfa_tune: re-rank the LDS-resident hot rows by the visits a sample of real
+        input makes (host bytes / numpy, or a CUDA uint8 tensor).  Returns the new info."""
+        l = _lib.lib()
+        if _is_torch(data):
+            import torch
+            if offsets is not None:
+                n, stride = offsets.numel() - 1, 0
+            elif n is None:
+                n = data.numel() // stride if stride else 0
+            _check(l.redgpu_dfa_tune_dev(self._h, data.data_ptr(),
+                                         offsets.data_ptr() if offsets is not None else None,
+                                         stride, n,
+                                         torch.cuda.current_stream(data.device).cuda_stream))
+            return self.info
+        a = _host_u8(data)
+        if offsets is not None:
+            offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+            n, stride = len(offsets) - 1, 0
+        elif n is None:
+            n = a.size // stride if stride else 0
+        _check(l.redgpu_dfa_tune(self._h, a.ctypes.data if a.size else None,
+                                 offsets.ctypes.data if offsets is not None else None, stride, n))
+        return self.info
+
     def serialized(self) -> bytes:
         p, n = C.c_void_p(), C.c_size_t()
         _check(_lib.lib().redgpu_dfa_serialized(self._h, C.byref(p), C.byref(n)))

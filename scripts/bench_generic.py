@@ -51,6 +51,11 @@ timeit(lambda: one_amd.match_batch(exe7, d9, 4, 0, stride=L8, n=n8), n8 * L8, "U
 t10 = W.fixed_lines(n8, L8, 10, alphabet=True)
 d10 = torch.from_numpy(t10).cuda()
 timeit(lambda: one_amd.match_batch(exe7, d10, 4, 0, stride=L8, n=n8), n8 * L8, "URI-V6 2^20 x 256 B text, no URL", it=3)
+t11 = W.fixed_lines(1 << 14, L8, 11, alphabet=True, plant=W.URI_PLANT, plant_every=8, plant_at=90)
+print("tune on a 4 MiB sample of other text with https URLs:", exe7.tune(t11, stride=L8, n=1 << 14))
+timeit(lambda: one_amd.match_batch(exe7, d9, 4, 0, stride=L8, n=n8), n8 * L8, "URI-V6 tuned: text, https://name URL every 8th line", it=3)
+timeit(lambda: one_amd.match_batch(exe7, d8, 4, 0, stride=L8, n=n8), n8 * L8, "URI-V6 tuned: text, IPv6 URL every 8th line (not in the sample)", it=3)
+timeit(lambda: one_amd.match_batch(exe7, d6, 4, 0, stride=L6, n=n6), n6 * L6, "URI-V6 tuned: 2^18 x 1 KiB random bytes", it=3)
 exe7g = one_amd.Executable(load_dfa("uri_v6"), force_generic=True)
 timeit(lambda: one_amd.match_batch(exe7g, d9, 4, 0, stride=L8, n=n8), n8 * L8, "  same (https URL), generic kernel + hot rows", it=3)
 exe7gg = one_amd.Executable(load_dfa("uri_v6"), force_generic=True, force_global=True)

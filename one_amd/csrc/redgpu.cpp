@@ -451,6 +451,20 @@ static int listHost(const redgpu_dfa *dfa, int listVerb, const uint8_t *data,
   return REDGPU_OK;
 }
 
+int redgpu_diag_read_dev(const redgpu_dfa *dfa, const void *data, uint64_t bytes, uint32_t *sink,
+                         void *stream) {
+  if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
+  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (!data || !sink) return fail(REDGPU_EAPI, "null buffer");
+  if (reinterpret_cast<uintptr_t>(data) % 16) return fail(REDGPU_EAPI, "buffer not 16-byte aligned");
+  DeviceScope scope(dfa->device);
+  if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  hipError_t e = launchDiagRead(data, bytes, sink, dfa->numCUs, static_cast<hipStream_t>(stream));
+  tlsKernel = "k_diag_read";
+  if (e != hipSuccess) return failHip(e, "kernel launch");
+  return REDGPU_OK;
+}
+
 int redgpu_dfa_tune_dev(redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,
                         uint64_t stride, uint64_t n, void *stream) {
   if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");

@@ -142,7 +142,11 @@ int redgpu_dfa_serialized(const redgpu_dfa *dfa, const void **reda, size_t *len)
  *                          (style 4 = styLast is the "matchLong" of BASELINE.json)
  *   redgpu_scan_batch  <-> scan<style,doLeader>(exec, ptr, len)   include/Matcher.h:159-160,498-554
  * The run-time-style overloads of the reference (Matcher.h:79-92, Matcher.cpp:53-67) are these
- * with do_leader = 1. */
+ * with do_leader = 1.
+ * Lines: offsets == NULL -> line i = data[i*stride, (i+1)*stride).  offsets != NULL (n + 1
+ * entries) -> line i = data[offsets[i], offsets[i+1] - stride): here `stride` is the number of
+ * trailing bytes each line carries that the matcher must not see - 0 normally, 1 for the
+ * delimiter-terminated lines redgpu_split_lines produces. */
 int redgpu_check_batch(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
                        const uint64_t *offsets, uint64_t stride, uint64_t n, int32_t *result);
 int redgpu_match_batch(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
@@ -217,6 +221,21 @@ int redgpu_match_all_batch_dev(const redgpu_dfa *dfa, int do_leader, const uint8
 int redgpu_advance_batch_dev(const redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,
                              uint64_t stride, uint64_t n, uint32_t *state, int32_t *result,
                              void *stream);
+
+/* The step BEFORE the path, on the device (the reference does it on the host:
+ * lib/Util.cpp:109-130 sampleLines, and every tool that walks a text blob line by line): finds
+ * the delimiters of a raw text buffer and writes the offsets[] array the ragged verbs take.
+ * A line is [start, delimiter); the next starts after the delimiter; bytes after the last
+ * delimiter are not a line (sampleLines' rule).  offsets[0] = 0 and offsets[k+1] = position
+ * just past the k-th delimiter, so line k = [offsets[k], offsets[k+1]) INCLUDES its delimiter:
+ * pass these offsets to the *_batch verbs with stride = 1 ("one trailing byte per line that the
+ * matcher must not see").  cap = lines offsets[] has room for (cap + 1 entries); *n_lines =
+ * delimiters FOUND, which may exceed cap (then only the first cap lines are stored).
+ * _dev: everything device-resident (n_lines too), asynchronous on `stream`. */
+int redgpu_split_lines(const redgpu_dfa *dfa, const uint8_t *data, uint64_t len, uint8_t delim,
+                       uint64_t *offsets, uint64_t cap, uint64_t *n_lines);
+int redgpu_split_lines_dev(const redgpu_dfa *dfa, const uint8_t *data, uint64_t len, uint8_t delim,
+                           uint64_t *offsets, uint64_t cap, uint64_t *n_lines, void *stream);
 
 /* Measurement aid, no counterpart in the reference: one streaming read of `bytes` of device
  * memory (16-byte aligned) on the handle's device, asynchronous on `stream` - the read-bandwidth

@@ -170,7 +170,8 @@ k_ragged(DevDfa d, Batch io) {
       }
       if (!mine[c]) { o = 0; e = 0; }  // idle lane: reads the buffer's first block, stores nothing
       base[c] = io.data + o;
-      len[c] = uint32_t(e - o);
+      // Batch::stride doubles as "trailing delimiter bytes per line" for ragged lines
+      len[c] = e - o >= io.stride ? uint32_t(e - o - io.stride) : 0u;
       const uint32_t nb = (len[c] + 63u) >> 6;
       lastBlk[c] = nb ? nb - 1 : 0;
       blocksWanted = nb > blocksWanted ? nb : blocksWanted;

@@ -34,7 +34,8 @@ struct DevDfa {
 struct Batch {
   const uint8_t  *data;
   const uint64_t *offsets; // n+1 entries, or nullptr => fixed stride
-  uint64_t stride;
+  uint64_t stride;         // fixed stride; with offsets: trailing delimiter bytes each line
+                           // carries and the verbs must not see (0, or 1 after redgpu_split_lines)
   uint64_t n;
   int32_t  *result;
   uint64_t *start;         // may be nullptr
@@ -71,6 +72,14 @@ hipError_t launchAdvance(const DevDfa &dfa, const Batch &b, uint32_t *state, con
 // match<styLast,false> consumes over the sample (hist zeroed by the caller).
 hipError_t launchVisits(const DevDfa &dfa, const Batch &b, uint32_t *hist, const LaunchCfg &cfg,
                         hipStream_t stream);
+
+// Line splitting (lib/Util.cpp:109-130's rule): offsets[0] = 0, offsets[k+1] = position after the
+// k-th delimiter, for k < cap; *nLines = delimiters found.  counts: uint32[splitChunks(len)],
+// bases: uint64[splitChunks(len)] scratch, both device memory.
+uint64_t splitChunks(uint64_t len);
+hipError_t launchSplitLines(const uint8_t *data, uint64_t len, uint8_t delim, uint64_t *offsets,
+                            uint64_t cap, uint64_t *nLines, uint32_t *counts, uint64_t *bases,
+                            hipStream_t stream);
 
 // bench.py's read-bandwidth calibration: one streaming pass over `bytes` (16-byte aligned).
 hipError_t launchDiagRead(const void *data, uint64_t bytes, uint32_t *sink, int numCUs,

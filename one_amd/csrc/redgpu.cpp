@@ -85,6 +85,8 @@ int runDev(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint8
   if (!result) return fail(REDGPU_EAPI, "null result buffer");
   if (!data && (offsets || stride)) return fail(REDGPU_EAPI, "null data buffer");
   if (!offsets && stride >= (1ull << 40)) return fail(REDGPU_ELIMIT, "stride too large");
+  if (offsets && stride > 16) return fail(REDGPU_EAPI, "with offsets, stride is the number of "
+                                                       "trailing bytes to drop per line (0..16)");
   DeviceScope scope(dfa->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   Batch b{data, offsets, stride, n, result, start, end};
@@ -447,6 +449,66 @@ static int listHost(const redgpu_dfa *dfa, int listVerb, const uint8_t *data,
     if (end) CH_TRY(hipMemcpy(end, dEnd, slots * 8, hipMemcpyDeviceToHost), "copy end");
   }
 #undef CH_TRY
+  cleanup();
+  return REDGPU_OK;
+}
+
+int redgpu_split_lines_dev(const redgpu_dfa *dfa, const uint8_t *data, uint64_t len, uint8_t delim,
+                           uint64_t *offsets, uint64_t cap, uint64_t *n_lines, void *stream) {
+  if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
+  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (!offsets || !n_lines) return fail(REDGPU_EAPI, "null output buffer");
+  if (len && !data) return fail(REDGPU_EAPI, "null data buffer");
+  if (splitChunks(len) >= (1ull << 31)) return fail(REDGPU_ELIMIT, "buffer too large");
+  DeviceScope scope(dfa->device);
+  if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const uint64_t nChunks = splitChunks(len);
+  void *scratch = nullptr;
+  // counts u32[nChunks] then bases u64[nChunks], stream-ordered so the call stays asynchronous
+  const size_t countBytes = (size_t(nChunks) * 4 + 15) & ~size_t(15);
+  HIP_TRY(hipMallocAsync(&scratch, countBytes + size_t(nChunks) * 8 + 16, s), "hipMallocAsync");
+  uint32_t *counts = static_cast<uint32_t *>(scratch);
+  uint64_t *bases = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(scratch) + countBytes);
+  hipError_t e = launchSplitLines(data, len, delim, offsets, cap, n_lines, counts, bases, s);
+  tlsKernel = "k_split_scatter";
+  hipError_t e2 = hipFreeAsync(scratch, s);
+  if (e != hipSuccess) return failHip(e, "kernel launch");
+  if (e2 != hipSuccess) return failHip(e2, "hipFreeAsync");
+  return REDGPU_OK;
+}
+
+int redgpu_split_lines(const redgpu_dfa *dfa, const uint8_t *data, uint64_t len, uint8_t delim,
+                       uint64_t *offsets, uint64_t cap, uint64_t *n_lines) {
+  if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
+  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (!offsets || !n_lines) return fail(REDGPU_EAPI, "null output buffer");
+  if (len && !data) return fail(REDGPU_EAPI, "null data buffer");
+  DeviceScope scope(dfa->device);
+  if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  uint8_t *dData = nullptr;
+  uint64_t *dOff = nullptr, *dN = nullptr;
+  auto cleanup = [&]() {
+    for (void *q : {(void *)dData, (void *)dOff, (void *)dN})
+      if (q) (void)hipFree(q);
+  };
+  int rc = REDGPU_OK;
+#define SP_TRY(expr, what)                                                    \
+  do {                                                                        \
+    hipError_t e_ = (expr);                                                   \
+    if (e_ != hipSuccess) { rc = failHip(e_, what); cleanup(); return rc; }   \
+  } while (0)
+  SP_TRY(hipMalloc(reinterpret_cast<void **>(&dData), len + 16), "hipMalloc data");
+  SP_TRY(hipMalloc(reinterpret_cast<void **>(&dOff), (cap + 1) * 8), "hipMalloc offsets");
+  SP_TRY(hipMalloc(reinterpret_cast<void **>(&dN), 8), "hipMalloc count");
+  if (len) SP_TRY(hipMemcpy(dData, data, len, hipMemcpyHostToDevice), "copy data");
+  rc = redgpu_split_lines_dev(dfa, dData, len, delim, dOff, cap, dN, nullptr);
+  if (rc != REDGPU_OK) { cleanup(); return rc; }
+  SP_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  SP_TRY(hipMemcpy(n_lines, dN, 8, hipMemcpyDeviceToHost), "copy count");
+  const uint64_t got = *n_lines < cap ? *n_lines : cap;
+  SP_TRY(hipMemcpy(offsets, dOff, (got + 1) * 8, hipMemcpyDeviceToHost), "copy offsets");
+#undef SP_TRY
   cleanup();
   return REDGPU_OK;
 }

@@ -114,7 +114,7 @@ class Executable:
         if _is_torch(data):
             import torch
             if offsets is not None:
-                n, stride = offsets.numel() - 1, 0
+                n = offsets.numel() - 1
             elif n is None:
                 n = data.numel() // stride if stride else 0
             _check(l.redgpu_dfa_tune_dev(self._h, data.data_ptr(),
@@ -125,7 +125,7 @@ class Executable:
         a = _host_u8(data)
         if offsets is not None:
             offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
-            n, stride = len(offsets) - 1, 0
+            n = len(offsets) - 1
         elif n is None:
             n = a.size // stride if stride else 0
         _check(l.redgpu_dfa_tune(self._h, a.ctypes.data if a.size else None,
@@ -171,7 +171,7 @@ def _run(verb: str, exe: Executable, style, do_leader, data, offsets, stride, n,
                     or not offsets.is_cuda or not offsets.is_contiguous()):
                 raise RedExceptApi("device offsets must be a contiguous int64 CUDA tensor")
             n = offsets.numel() - 1
-            stride = 0
+            stride = int(stride or 0)  # with offsets: trailing bytes to drop per line
         elif n is None:
             n = data.numel() // stride if stride else 0
         if out is None:
@@ -197,7 +197,7 @@ def _run(verb: str, exe: Executable, style, do_leader, data, offsets, stride, n,
     if offsets is not None:
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = len(offsets) - 1
-        stride = 0
+        stride = int(stride or 0)  # with offsets: trailing bytes to drop per line
         if len(offsets) and int(offsets[-1]) > a.size:
             raise RedExceptApi("offsets run past the data buffer")
     else:
@@ -258,7 +258,7 @@ def collect_batch(exe, data, cap, *, offsets=None, stride=0, n=None):
     if offsets is not None:
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = len(offsets) - 1
-        stride = 0
+        stride = int(stride or 0)  # with offsets: trailing bytes to drop per line
     elif n is None:
         n = a.size // stride if stride else 0
     counts = np.zeros(n, dtype=np.uint64)
@@ -287,7 +287,7 @@ def match_all_batch(exe, data, cap, do_leader=True, *, offsets=None, stride=0, n
     if offsets is not None:
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = len(offsets) - 1
-        stride = 0
+        stride = int(stride or 0)  # with offsets: trailing bytes to drop per line
     elif n is None:
         n = a.size // stride if stride else 0
     counts = np.zeros(n, dtype=np.uint64)
@@ -328,7 +328,7 @@ def advance_batch(exe, data, state, *, offsets=None, stride=0, n=None, out=None)
                     or not offsets.is_cuda or not offsets.is_contiguous()):
                 raise RedExceptApi("device offsets must be a contiguous int64 CUDA tensor")
             n = offsets.numel() - 1
-            stride = 0
+            stride = int(stride or 0)  # with offsets: trailing bytes to drop per line
         elif n is None:
             n = data.numel() // stride if stride else 0
         if (not _is_torch(state) or state.numel() != n or state.element_size() != 4 or
@@ -343,7 +343,7 @@ def advance_batch(exe, data, state, *, offsets=None, stride=0, n=None, out=None)
     if offsets is not None:
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = len(offsets) - 1
-        stride = 0
+        stride = int(stride or 0)  # with offsets: trailing bytes to drop per line
     elif n is None:
         n = a.size // stride if stride else 0
     if not (isinstance(state, np.ndarray) and state.dtype == np.uint32 and state.size == n and
@@ -354,6 +354,37 @@ def advance_batch(exe, data, state, *, offsets=None, stride=0, n=None, out=None)
                                   offsets.ctypes.data if offsets is not None else None, stride,
                                   n, state.ctypes.data, res.ctypes.data))
     return res
+
+
+def split_lines(exe, data, delim=b"\n", cap=None):
+    """redgpu_split_lines: offsets of the delimiter-terminated lines of a raw text buffer, found
+    on the device (the rule of lib/Util.cpp:109-130: bytes after the last delimiter are not a
+    line).  Line k = data[offsets[k] : offsets[k+1]] INCLUDING its delimiter - pass the offsets
+    to the *_batch verbs with stride=1.  Returns (offsets, n_found): numpy uint64[min(n, cap)+1]
+    for host input; for a CUDA uint8 tensor, an int64 tensor of cap+1 entries and a 1-element
+    int64 tensor, both on the device, asynchronously on the current stream."""
+    l = _lib.lib()
+    d = delim[0] if isinstance(delim, (bytes, bytearray)) else int(delim)
+    if _is_torch(data):
+        import torch
+        if not data.is_cuda or data.dtype != torch.uint8 or not data.is_contiguous():
+            raise RedExceptApi("device input must be a contiguous uint8 CUDA tensor")
+        if cap is None:
+            raise RedExceptApi("device split_lines needs cap (room in the offsets tensor)")
+        offs = torch.empty(cap + 1, dtype=torch.int64, device=data.device)
+        cnt = torch.empty(1, dtype=torch.int64, device=data.device)
+        _check(l.redgpu_split_lines_dev(exe._h, data.data_ptr(), data.numel(), d, offs.data_ptr(),
+                                        cap, cnt.data_ptr(),
+                                        torch.cuda.current_stream(data.device).cuda_stream))
+        return offs, cnt
+    a = _host_u8(data)
+    if cap is None:
+        cap = int(a.size)  # no more lines than bytes
+    offs = np.zeros(cap + 1, dtype=np.uint64)
+    cnt = C.c_uint64(0)
+    _check(l.redgpu_split_lines(exe._h, a.ctypes.data if a.size else None, a.size, d,
+                                offs.ctypes.data, cap, C.byref(cnt)))
+    return offs[: min(cnt.value, cap) + 1], int(cnt.value)
 
 
 class StatefulMatcher:

@@ -296,6 +296,26 @@ class CpuOracle(_Batchable):
 
 STATE_INITIAL = 0xFFFFFFFF
 
+
+def split_lines(data, delim: int = 0x0A) -> np.ndarray:
+    """The line rule of lib/Util.cpp:109-130 (sampleLines: `rv.emplace_back(start, it)` at every
+    '\n', `start = it + 1`; what follows the last '\n' is never emitted), as offsets:
+    offsets[0] = 0, offsets[k+1] = index just past the k-th delimiter.  Line k is
+    data[offsets[k] : offsets[k+1] - 1] (its delimiter excluded)."""
+    a = _as_u8(data)
+    ends = np.flatnonzero(a == delim).astype(np.uint64) + np.uint64(1)
+    return np.concatenate([np.zeros(1, dtype=np.uint64), ends])
+
+
+def split_lines_loop(data: bytes, delim: int = 0x0A):
+    """The same rule written as sampleLines' own loop (small inputs): list of line bytes."""
+    out, start = [], 0
+    for it, ch in enumerate(data):
+        if ch == delim:
+            out.append(bytes(data[start:it]))
+            start = it + 1
+    return out
+
 # ------------------------------------------------------------------------------------------
 _libref = None
 

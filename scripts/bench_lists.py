@@ -47,3 +47,24 @@ for n, L in [(1 << 20, 64), (1 << 18, 4096), (1 << 20, 96)]:
         print("%-9s %8d x %5d B  %8.1f us  %7.1f GB/s  %s" % (label, n, L, ms * 1e3, total / ms / 1e6, one_amd.last_kernel()), flush=True)
     del data
     torch.cuda.empty_cache()
+
+# line splitting on the device, then matching the split lines (delimiter dropped)
+import numpy as np
+from one_amd import workloads as W
+for total, p_nl in ((1 << 26, 1 / 64), (1 << 28, 1 / 144)):
+    host = W.alphabet_bytes(total, 12).copy()
+    rng = np.random.default_rng(1)
+    host[rng.random(total) < p_nl] = 0x0A
+    dev = torch.from_numpy(host).cuda()
+    cap = int(total * p_nl * 1.2) + 16
+    ms = timed(lambda: one_amd.split_lines(exe, dev, cap=cap), 20)
+    offs, cnt = one_amd.split_lines(exe, dev, cap=cap)
+    n = int(cnt.item())
+    print("split     %9d bytes -> %8d lines  %8.1f us  %7.1f GB/s" % (total, n, ms * 1e3, total / ms / 1e6), flush=True)
+    o = offs[:n + 1].contiguous()
+    res = torch.empty(n, dtype=torch.int32, device="cuda")
+    st = torch.empty(n, dtype=torch.int64, device="cuda")
+    en = torch.empty(n, dtype=torch.int64, device="cuda")
+    ms = timed(lambda: one_amd.match_batch(exe, dev, 4, False, offsets=o, stride=1, out=(res, st, en)), 20)
+    print("match     same lines (delimiter dropped)      %8.1f us  %7.1f GB/s  %s" % (ms * 1e3, total / ms / 1e6, one_amd.last_kernel()), flush=True)
+    del dev

@@ -296,6 +296,70 @@ def test_tune_reranks_hot_rows_results_unchanged():
     assert small.tune(sample, stride=L, n=n)["table_kind"] == 1
 
 
+def test_split_lines_on_device_then_match():
+    """redgpu_split_lines: delimiter scan + prefix sum on the device vs the rule of
+    lib/Util.cpp:109-130 (oracle.split_lines), on host and device buffers, aligned and unaligned,
+    with runs of empty lines, no trailing newline, cap overflow; then the offsets feed the
+    ragged verbs with stride=1 (the delimiter dropped) and must give what the oracle gives on
+    the same lines with their delimiters removed."""
+    import torch
+    blob = load_dfa("uri")
+    exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
+    rng = np.random.default_rng(9)
+    for n_bytes, p_nl in ((0, 0.1), (1, 1.0), (15, 0.3), (100000, 0.02), (3_000_001, 0.01),
+                          (70000, 0.0), (40000, 1.0)):
+        text = W.alphabet_bytes(n_bytes + 3, 77 + n_bytes)[3:].copy()   # unaligned view
+        nl = rng.random(n_bytes) < p_nl
+        text[nl] = 0x0A
+        if n_bytes > 200:   # plant URLs so that some lines match
+            for k in range(0, n_bytes - 100, 997):
+                text[k:k + len(W.URI_PLANT)] = np.frombuffer(W.URI_PLANT, dtype=np.uint8)
+        exp = O.split_lines(text)
+        offs, found = one_amd.split_lines(exe, text)
+        assert found == len(exp) - 1 and np.array_equal(offs, exp), (n_bytes, p_nl)
+        # device form; cap smaller than the number of lines keeps the first cap
+        dev = torch.from_numpy(np.ascontiguousarray(text)).cuda()
+        cap = max(1, (len(exp) - 1) // 2)
+        doffs, dcnt = one_amd.split_lines(exe, dev, cap=cap)
+        torch.cuda.synchronize()
+        assert int(dcnt.item()) == len(exp) - 1
+        k = min(cap, len(exp) - 1)
+        assert np.array_equal(doffs[:k + 1].cpu().numpy().astype(np.uint64), exp[:k + 1])
+        if len(exp) < 2:
+            continue
+        # match the lines, delimiter dropped
+        n = len(exp) - 1
+        keep = text[:int(exp[-1])]
+        compact = keep[keep != 0x0A]
+        coffs = exp - np.arange(n + 1, dtype=np.uint64)
+        er, es, ee = cpu.batch("match", 4, 0, compact, offsets=coffs, threads=4)
+        r, s, e = one_amd.match_batch(exe, text, 4, 0, offsets=offs, stride=1)
+        assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee)
+        for sty, lead in ((1, 1), (5, 0)):
+            assert np.array_equal(one_amd.check_batch(exe, text, sty, lead, offsets=offs, stride=1),
+                                  cpu.batch("check", sty, lead, compact, offsets=coffs)[0])
+        if n_bytes <= 100000:
+            assert np.array_equal(one_amd.scan_batch(exe, text, 1, 1, offsets=offs, stride=1),
+                                  cpu.batch("scan", 1, 1, compact, offsets=coffs, threads=4)[0])
+            got = one_amd.collect_batch(exe, text, 4, offsets=offs, stride=1)
+            expc = cpu.collect_batch(compact, 4, offsets=coffs)
+            assert np.array_equal(got[0], expc[0])
+    # end to end on the device: split -> match, nothing leaves HBM in between
+    big = W.alphabet_bytes(1 << 22, 5).copy()
+    big[rng.random(big.size) < 0.01] = 0x0A
+    exp = O.split_lines(big)
+    dev = torch.from_numpy(big).cuda()
+    doffs, dcnt = one_amd.split_lines(exe, dev, cap=len(exp) + 10)
+    n = int(dcnt.item())
+    assert n == len(exp) - 1
+    r, s, e = one_amd.match_batch(exe, dev, 4, 0, offsets=doffs[:n + 1].contiguous(), stride=1)
+    keep = big[:int(exp[-1])]
+    er, es, ee = cpu.batch("match", 4, 0, keep[keep != 0x0A],
+                           offsets=exp - np.arange(n + 1, dtype=np.uint64), threads=8)
+    assert np.array_equal(r.cpu().numpy(), er)
+    assert np.array_equal(e.cpu().numpy().astype(np.uint64), ee)
+
+
 def test_edge_cases():
     exe = one_amd.Executable(load_dfa("err"))
     cpu = O.CpuOracle(load_dfa("err"))

@@ -156,3 +156,15 @@ def test_match_all_and_stateful_kat_and_vectors():
 def cpu_adv(cpu, data, state, i, lo, hi):
     st = state[i:i + 1]
     return int(cpu.advance_batch(data[lo:hi], st, offsets=np.array([0, hi - lo], dtype=np.uint64))[0])
+
+
+def test_split_lines_rule():
+    """lib/Util.cpp:109-130: lines end at a newline, the newline is not part of the line, and a
+    trailing fragment without one is not a line - offsets form vs the loop form."""
+    rng = np.random.default_rng(5)
+    for text in (b"", b"\n", b"abc", b"abc\n", b"a\n\nbc\nrest", b"\n\n\n",
+                 bytes(rng.choice(np.frombuffer(b"ab\n", dtype=np.uint8), 500))):
+        offs = O.split_lines(text)
+        lines = [text[int(offs[k]):int(offs[k + 1]) - 1] for k in range(len(offs) - 1)]
+        assert lines == O.split_lines_loop(text)
+        assert int(offs[-1]) == (text.rfind(b"\n") + 1)

@@ -61,6 +61,8 @@ typedef struct redgpu_opts {
 
 #define REDGPU_F_FORCE_GENERIC 1u /* never pick the specialised fixed-stride kernels */
 #define REDGPU_F_FORCE_GLOBAL  2u /* keep the transition table in HBM/L2 even if it fits LDS */
+#define REDGPU_F_NO_BUCKETING  8u /* ragged fast path: walk lines in input order instead of
+                                     bucketing them by length first (tests, tuning) */
 #define REDGPU_F_FORCE_HOT     4u /* a table too big for LDS always gets hot rows in LDS, even
                                      when the visit model finds no locality (tests, tuning) */
 
@@ -195,7 +197,10 @@ int redgpu_advance_batch(const redgpu_dfa *dfa, const uint8_t *data, const uint6
 
 /* ---- the same verbs over DEVICE-resident buffers, asynchronous on `stream` ---------------
  * data/offsets/result/start/end are device pointers on the handle's device; `stream` is a
- * hipStream_t (NULL = the default stream).  Nothing is allocated, copied or synchronised. */
+ * hipStream_t (NULL = the default stream).  Nothing is copied or synchronised; the only
+ * allocation is the ragged fast path's scratch (4 bytes per line for its length-bucketing
+ * pass), kept per host thread and stream and re-used by later calls - it is (re)allocated, with
+ * a device synchronisation, only when a call needs more than the cached buffer holds. */
 int redgpu_check_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
                            const uint64_t *offsets, uint64_t stride, uint64_t n,
                            int32_t *result, void *stream);

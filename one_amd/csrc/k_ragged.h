@@ -14,11 +14,12 @@
 //  * a wave walks as many blocks as its longest line needs (wave-uniform trip count from a
 //    cross-lane max); finished lanes re-read their last block (L1/L2 hits).
 //  * lines start at arbitrary byte offsets: 16-byte loads at unaligned addresses (the memory
-//    pipeline splits them).  Block reads run up to 63 bytes past a line's end, so lines that
-//    end within the last 64 bytes of the input buffer are NOT walked here (they would read
-//    past the buffer): they are left to a second, tiny launch of k_generic restricted to
-//    exactly those lines (Batch::tailOnly).  Requests stay unconditional and branch-free, so
-//    the compiler's in-order vmcnt counts stay exact.
+//    pipeline splits them).  Block reads run up to 63 bytes past a line's end: a block that
+//    would reach past the end of the input buffer is read from `pad` instead - a 192-byte
+//    copy of the buffer's last 128 bytes followed by zeros, made by k_tail_pad just before.
+//    (An earlier form left those lines to a one-lane generic walk: 25+ us of pure latency
+//    for a single 256-byte line, serialised behind this kernel.)  Requests stay unconditional,
+//    so the compiler's in-order vmcnt counts stay exact.
 //  * an empty line reports the initial state's result (Matcher.h:379,437 with no iterations).
 #pragma once
 
@@ -149,11 +150,13 @@ k_ragged(DevDfa d, Batch io) {
   __syncthreads();
 
   const uint64_t total = io.offsets[io.n];
-  if (total < 64) return;  // every line is a "tail" line: k_generic takes them all
+  const uint64_t padStart = total >= 128 ? total - 128 : 0;  // pad[] = data[padStart, total) + 0s
+  // the bucketing pass's verdict sits right behind the permutation
+  const bool usePerm = io.perm && io.perm[io.n] != 0;
   const int32_t initResult = init >= firstAccept ? ldsRes[init] : 0;
 
   for (uint64_t tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
-    const uint8_t *base[CH];
+    uint64_t lineOff[CH];
     uint32_t len[CH], lastBlk[CH];
     uint64_t ln[CH];
     bool mine[CH];
@@ -164,12 +167,13 @@ k_ragged(DevDfa d, Batch io) {
       uint64_t o = 0, e = 0;
       mine[c] = false;
       if (ln[c] < io.n) {
+        if (usePerm) ln[c] = io.perm[ln[c]];  // lines bucketed by length: see launchRaggedT
         o = io.offsets[ln[c]];
         e = io.offsets[ln[c] + 1];
-        mine[c] = e + 64 <= total;  // else: a tail line, left to k_generic (Batch::tailOnly)
+        mine[c] = true;
       }
       if (!mine[c]) { o = 0; e = 0; }  // idle lane: reads the buffer's first block, stores nothing
-      base[c] = io.data + o;
+      lineOff[c] = o;
       // Batch::stride doubles as "trailing delimiter bytes per line" for ragged lines
       len[c] = e - o >= io.stride ? uint32_t(e - o - io.stride) : 0u;
       const uint32_t nb = (len[c] + 63u) >> 6;
@@ -193,7 +197,9 @@ k_ragged(DevDfa d, Batch io) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           const uint32_t rr = r < lastBlk[c] ? r : lastBlk[c];
-          blk[c].p[k] = *reinterpret_cast<const uint4 *>(base[c] + uint64_t(rr) * 64 + 16 * k);
+          const uint64_t bo = lineOff[c] + uint64_t(rr) * 64;
+          const uint8_t *src = bo + 64 <= total ? io.data + bo : io.pad + (bo - padStart);
+          blk[c].p[k] = *reinterpret_cast<const uint4 *>(src + 16 * k);
         }
       }
     };
@@ -288,12 +294,185 @@ k_ragged(DevDfa d, Batch io) {
 #undef RG_I_ACC
 #undef RG_I_START
 
+// ---- length bucketing ---------------------------------------------------------------------
+// A wave of k_ragged runs for as many 64-byte blocks as its LONGEST line needs; on text whose
+// line lengths are skewed (geometric: the longest of a wave's 128 lines is ~5x the mean) most
+// lanes idle.  A counting sort of the line indices by block count (descending, so the heavy
+// tiles run first and the tail of the launch is made of light ones) puts lines of like length
+// in the same wave.  Three small kernels over offsets[] only (8 bytes per line); each workgroup
+// owns a contiguous range of lines so that lines of one bucket keep their memory order.
+constexpr int kBucketCount = 64;
+constexpr int kBucketThreads = 256;
+
+__device__ __forceinline__ uint32_t bucketOf(const uint64_t *offsets, uint64_t line, uint64_t trim) {
+  uint64_t len = offsets[line + 1] - offsets[line];
+  len = len >= trim ? len - trim : 0;
+  const uint64_t nb = (len + 63) >> 6;
+  // descending: bucket 0 = the longest lines (63+ blocks), bucket 63 = empty lines
+  return uint32_t(kBucketCount - 1 - (nb < kBucketCount - 1 ? nb : kBucketCount - 1));
+}
+
+// pass 1: per-workgroup length histograms (and, by workgroup 0, the tail pad of k_tail_pad)
+__global__ void __launch_bounds__(kBucketThreads)
+k_bucket_hist(const uint8_t *data, const uint64_t *offsets, uint64_t n, uint64_t trim,
+              uint64_t perBlock, uint32_t *hist /* [bucket][block] */, uint8_t *pad) {
+  __shared__ uint32_t h[kBucketCount];
+  if (threadIdx.x < kBucketCount) h[threadIdx.x] = 0;
+  if (blockIdx.x == 0 && threadIdx.x < 192) {
+    const uint64_t total = offsets[n];
+    const uint64_t i = (total >= 128 ? total - 128 : 0) + threadIdx.x;
+    pad[threadIdx.x] = i < total ? data[i] : uint8_t(0);
+  }
+  __syncthreads();
+  const uint64_t lo = uint64_t(blockIdx.x) * perBlock;
+  const uint64_t hi = lo + perBlock < n ? lo + perBlock : n;
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += kBucketThreads)
+    atomicAdd(&h[bucketOf(offsets, i, trim)], 1u);
+  __syncthreads();
+  if (threadIdx.x < kBucketCount) hist[uint64_t(threadIdx.x) * gridDim.x + blockIdx.x] = h[threadIdx.x];
+}
+
+// pass 2: every workgroup derives its own scatter bases from the whole histogram table (64 x
+// <= 256 entries: cheaper than a separate scan kernel and its dispatch), reaches the same
+// verdict, and scatters its lines' indices.  Verdict: a wave of 128 lines drawn at random from
+// the length histogram spends 128 x E[longest] blocks where its lines need 128 x mean;
+// bucketing is applied when that ratio exceeds 1.5 (uniform 32..256-byte lines: 1.48;
+// geometric lengths: ~5).  Workgroup 0 publishes the verdict for k_ragged.
+__global__ void __launch_bounds__(kBucketThreads)
+k_bucket_scatter(const uint64_t *offsets, uint64_t n, uint64_t trim, uint64_t perBlock,
+                 const uint32_t *hist, uint32_t *perm, uint32_t *usePerm) {
+  __shared__ uint32_t rowTot[kBucketCount], rowBefore[kBucketCount], cur[kBucketCount];
+  __shared__ uint32_t verdict;
+  const uint32_t nBlocks = gridDim.x;
+  {
+    // 4 threads per bucket row
+    const uint32_t k = threadIdx.x >> 2, part = threadIdx.x & 3;
+    uint32_t tot = 0, before = 0;
+    for (uint32_t blk = part; blk < nBlocks; blk += 4) {
+      const uint32_t v = hist[uint64_t(k) * nBlocks + blk];
+      tot += v;
+      before += blk < blockIdx.x ? v : 0;
+    }
+    tot += __shfl_xor(tot, 1); tot += __shfl_xor(tot, 2);
+    before += __shfl_xor(before, 1); before += __shfl_xor(before, 2);
+    if (part == 0) { rowTot[k] = tot; rowBefore[k] = before; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    // lane k = bucket k (descending length: bucket k holds lines of 63 - k blocks)
+    const uint32_t k = threadIdx.x;
+    uint32_t incl = rowTot[k];
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t u = __shfl_up(incl, o);
+      if (k >= uint32_t(o)) incl += u;
+    }
+    cur[k] = incl - rowTot[k] + rowBefore[k];
+    const float total = float(__shfl(incl, 63));
+    // P(length <= 63 - k blocks) = (lines in buckets >= k) / total
+    const float geq = total > 0.f ? (total - float(incl - rowTot[k])) / total : 0.f;
+    float g = geq;                       // ^128 by squaring
+    for (int q = 0; q < 7; ++q) g *= g;
+    const float gNext = k < 63 ? __shfl_down(g, 1) : 0.f;   // P(max <= 62 - k)
+    const float nbk = float(63 - k);
+    float emax = nbk * (g - (k < 63 ? gNext : 0.f));
+    float mean = total > 0.f ? nbk * float(rowTot[k]) / total : 0.f;
+    for (int o = 32; o; o >>= 1) { emax += __shfl_xor(emax, o); mean += __shfl_xor(mean, o); }
+    if (k == 0) {
+      verdict = (mean > 0.f && emax > 1.5f * mean) ? 1u : 0u;
+      if (blockIdx.x == 0) *usePerm = verdict;
+    }
+  }
+  __syncthreads();
+  if (!verdict) return;
+  const uint64_t lo = uint64_t(blockIdx.x) * perBlock;
+  const uint64_t hi = lo + perBlock < n ? lo + perBlock : n;
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += kBucketThreads)
+    perm[atomicAdd(&cur[bucketOf(offsets, i, trim)], 1u)] = uint32_t(i);
+}
+
+constexpr uint64_t kBucketMinLines = 16384;
+
+// Scratch for the ragged launch (tail pad, permutation, histograms), cached per host thread and
+// (device, stream): work queued on one stream runs in order, so the next call on that stream may
+// reuse the buffer the previous one used; another stream or another thread gets its own.
+// hipMallocAsync/hipFreeAsync per call cost ~12 us of host time and a bubble on the stream.
+// A buffer is only released (hipFree: synchronising) when it has to grow or its slot is
+// recycled; at thread exit it is left to the runtime's teardown.
+struct RaggedScratch {
+  int dev = -1;
+  hipStream_t stream = nullptr;
+  void *ptr = nullptr;
+  size_t bytes = 0;
+};
+
+inline hipError_t raggedScratch(hipStream_t stream, size_t bytes, void **out) {
+  constexpr int kSlots = 4;
+  thread_local RaggedScratch slots[kSlots];
+  thread_local int victim = 0;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  RaggedScratch *slot = nullptr;
+  for (auto &sl : slots)
+    if (sl.ptr && sl.dev == dev && sl.stream == stream) slot = &sl;
+  if (slot && slot->bytes >= bytes) { *out = slot->ptr; return hipSuccess; }
+  if (!slot) {
+    for (auto &sl : slots)
+      if (!sl.ptr) { slot = &sl; break; }
+    if (!slot) { slot = &slots[victim]; victim = (victim + 1) % kSlots; }
+  }
+  if (slot->ptr) {
+    (void)hipFree(slot->ptr);  // waits for the work that may still be using it
+    slot->ptr = nullptr;
+  }
+  const size_t want = bytes + bytes / 2 + 4096;
+  e = hipMalloc(&slot->ptr, want);
+  if (e != hipSuccess) { slot->ptr = nullptr; return e; }
+  slot->dev = dev;
+  slot->stream = stream;
+  slot->bytes = want;
+  *out = slot->ptr;
+  return hipSuccess;
+}
+
+// pad[0..192) = data[padStart, total) followed by zeros (see the header comment)
+__global__ void __launch_bounds__(192)
+k_tail_pad(const uint8_t *data, const uint64_t *offsets, uint64_t n, uint8_t *pad) {
+  const uint64_t total = offsets[n];
+  const uint64_t padStart = total >= 128 ? total - 128 : 0;
+  const uint64_t i = padStart + threadIdx.x;
+  pad[threadIdx.x] = i < total ? data[i] : uint8_t(0);
+}
+
 template <int MODE>
 hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
                          hipStream_t stream) {
   const uint64_t linesPerTile = uint64_t(kStreamThreads) * kStreamChains;
   const uint64_t tiles = (b.n + linesPerTile - 1) / linesPerTile;
   const uint64_t blocks = tiles < uint64_t(cfg.numCUs) ? tiles : uint64_t(cfg.numCUs);
-  hipLaunchKernelGGL(k_ragged<MODE>, dim3(uint32_t(blocks)), dim3(kStreamThreads), 0, stream, d, b);
+  const bool bucket = b.n >= kBucketMinLines && b.n < (1ull << 32) && !cfg.noBucketing;
+  // scratch (cached per thread and stream, see raggedScratch):
+  //   [pad 192 -> 256][perm u32[n]][usePerm u32][pad to 16][hist u32[64 * nb]]
+  const uint32_t nb = bucket ? uint32_t(b.n / 4096 < 256 ? (b.n + 4095) / 4096 : 256) : 0;
+  const size_t permBytes = bucket ? (size_t(b.n + 1) * 4 + 15) & ~size_t(15) : 0;
+  void *scratch = nullptr;
+  hipError_t e = raggedScratch(stream, 256 + permBytes + size_t(kBucketCount) * nb * 4, &scratch);
+  if (e != hipSuccess) return e;
+  Batch rb = b;
+  uint8_t *pad = static_cast<uint8_t *>(scratch);
+  rb.pad = pad;
+  if (bucket) {
+    const uint64_t perBlock = (b.n + nb - 1) / nb;
+    uint32_t *perm = reinterpret_cast<uint32_t *>(pad + 256);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(pad + 256 + permBytes);
+    hipLaunchKernelGGL(k_bucket_hist, dim3(nb), dim3(kBucketThreads), 0, stream, b.data, b.offsets,
+                       b.n, b.stride, perBlock, hist, pad);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(nb), dim3(kBucketThreads), 0, stream, b.offsets, b.n,
+                       b.stride, perBlock, hist, perm, perm + b.n);
+    rb.perm = perm;
+  } else {
+    hipLaunchKernelGGL(k_tail_pad, dim3(1), dim3(192), 0, stream, b.data, b.offsets, b.n, pad);
+  }
+  hipLaunchKernelGGL(k_ragged<MODE>, dim3(uint32_t(blocks)), dim3(kStreamThreads), 0, stream, d, rb);
   return hipGetLastError();
 }

@@ -40,13 +40,15 @@ struct Batch {
   int32_t  *result;
   uint64_t *start;         // may be nullptr
   uint64_t *end;           // may be nullptr
-  uint32_t tailOnly = 0;   // k_generic: only lines ending within the buffer's last 64 bytes
   uint32_t *state = nullptr; // advance only: per-line StatefulMatcher state, in/out
+  const uint32_t *perm = nullptr; // k_ragged only: slot -> line (lines bucketed by length)
+  const uint8_t *pad = nullptr;   // k_ragged only: copy of the buffer's last 128 bytes + zeros
 };
 
 struct LaunchCfg {
   int numCUs;
   int forceGeneric;
+  int noBucketing = 0;  // k_ragged: keep lines in input order (REDGPU_F_NO_BUCKETING)
 };
 
 // Launches the kernel for (verb, style, doLeader) on `stream`; returns hipSuccess or the

@@ -386,10 +386,6 @@ k_generic(DevDfa d, Batch b, int verb, int style, int lead) {
     if (b.offsets) {
       const uint64_t o = b.offsets[line];
       const uint64_t e = b.offsets[line + 1];
-      if (b.tailOnly) {  // the lines k_ragged leaves behind (see k_ragged.h)
-        const uint64_t total = b.offsets[b.n];
-        if (total >= 64 && e + 64 <= total) continue;
-      }
       p = b.data + o;
       n = e - o >= b.stride ? e - o - b.stride : 0;  // stride = trailing bytes to drop (ragged)
     } else {
@@ -1254,8 +1250,8 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
   }
 
   // Ragged lines, fused-u8 table, styles Last / Full of check / match, no leader to honour:
-  // k_ragged walks every line that ends >= 64 bytes before the end of the buffer, k_generic
-  // (tailOnly) the few that do not.
+  // k_ragged walks every line; blocks that would reach past the end of the buffer come from a
+  // padded copy of its last bytes.
   const bool raggedOk = !cfg.forceGeneric && fastPathEligible(d) && b.offsets &&
                         (verb == kCheck || verb == kMatch) &&
                         (style == kStyLast || style == kStyFull) && !lead &&
@@ -1271,10 +1267,7 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
       if (sb.start) { *kernelName = "k_ragged<full,start>"; e = launchRaggedT<kSmFullStart>(d, sb, cfg, stream); }
       else { *kernelName = "k_ragged<full>"; e = launchRaggedT<kSmFull>(d, sb, cfg, stream); }
     }
-    if (e != hipSuccess) return e;
-    Batch tb = b;
-    tb.tailOnly = 1;
-    return launchGeneric<REDGPU_TAB_LDS_FUSED_U8>(d, tb, verb, style, 0, cfg, stream);
+    return e;
   }
 
   *kernelName = "k_generic";

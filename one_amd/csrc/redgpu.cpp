@@ -90,7 +90,8 @@ int runDev(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint8
   DeviceScope scope(dfa->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   Batch b{data, offsets, stride, n, result, start, end};
-  LaunchCfg cfg{dfa->numCUs, (dfa->flags & REDGPU_F_FORCE_GENERIC) ? 1 : 0};
+  LaunchCfg cfg{dfa->numCUs, (dfa->flags & REDGPU_F_FORCE_GENERIC) ? 1 : 0,
+                (dfa->flags & REDGPU_F_NO_BUCKETING) ? 1 : 0};
   const char *name = "";
   hipError_t e = launchBatch(dfa->dev, b, verb, style, doLeader ? 1 : 0, cfg, stream, &name);
   tlsKernel = name;

@@ -76,7 +76,8 @@ class Executable:
     no HIP call; batch verbs on it raise RedExceptApi)."""
 
     def __init__(self, serialized: bytes, device=None, *, force_generic=False,
-                 force_global=False, force_hot=False, lds_table_max=0):
+                 force_global=False, force_hot=False, no_bucketing=False,
+                 lds_table_max=0):
         if serialized is None or len(serialized) == 0:
             raise RedExceptApi("serialized dfa string_view is empty")  # Executable.cpp:66
         o = _lib.Opts()
@@ -85,7 +86,8 @@ class Executable:
         o.lds_table_max = lds_table_max
         o.flags = (_lib.F_FORCE_GENERIC if force_generic else 0) | \
                   (_lib.F_FORCE_GLOBAL if force_global else 0) | \
-                  (_lib.F_FORCE_HOT if force_hot else 0)
+                  (_lib.F_FORCE_HOT if force_hot else 0) | \
+                  (_lib.F_NO_BUCKETING if no_bucketing else 0)
         self._h = C.c_void_p()
         blob = bytes(serialized)
         _check(_lib.lib().redgpu_dfa_create(blob, len(blob), C.byref(o), C.byref(self._h)))

@@ -360,6 +360,34 @@ def test_split_lines_on_device_then_match():
     assert np.array_equal(e.cpu().numpy().astype(np.uint64), ee)
 
 
+@pytest.mark.parametrize("name", ["syn256", "uri"])
+def test_ragged_length_bucketing_vs_oracle(name):
+    """k_ragged behind its length-bucketing pass (>= 16384 lines): skewed line lengths - many
+    empty and short lines, a geometric tail, a few lines of 64+ blocks - results land on the
+    right lines whatever order the kernel walks them in; same answers with bucketing off."""
+    blob = load_dfa(name)
+    cpu = O.CpuOracle(blob)
+    rng = np.random.default_rng(12)
+    n = 50000
+    lens = rng.geometric(1 / 70, n).astype(np.int64) - 1
+    lens[rng.random(n) < 0.05] = 0
+    lens[rng.integers(0, n, 20)] = rng.integers(4000, 9000, 20)
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    data = (W.random_bytes if name == "syn256" else W.alphabet_bytes)(int(offsets[-1]), 13).copy()
+    if name == "uri":
+        for k in range(0, data.size - 100, 1500):
+            data[k:k + len(W.URI_PLANT)] = np.frombuffer(W.URI_PLANT, dtype=np.uint8)
+    er, es, ee = cpu.batch("match", 4, 0, data, offsets=offsets, threads=8)
+    ef = cpu.batch("check", 5, 0, data, offsets=offsets, threads=8)[0]
+    for kw in ({}, {"no_bucketing": True}):
+        exe = one_amd.Executable(blob, **kw)
+        r, s, e = one_amd.match_batch(exe, data, 4, 0, offsets=offsets)
+        assert one_amd.last_kernel().startswith("k_ragged")
+        assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee)
+        assert np.array_equal(one_amd.check_batch(exe, data, 5, 0, offsets=offsets), ef)
+
+
 def test_edge_cases():
     exe = one_amd.Executable(load_dfa("err"))
     cpu = O.CpuOracle(load_dfa("err"))

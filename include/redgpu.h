@@ -195,6 +195,22 @@ int redgpu_match_all_batch(const redgpu_dfa *dfa, int do_leader, const uint8_t *
 int redgpu_advance_batch(const redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,
                          uint64_t stride, uint64_t n, uint32_t *state, int32_t *result);
 
+/*   redgpu_replace_batch <-> replace<style,doLeader>(exec, ptr, len, repl, out, max)
+ *                            include/Matcher.h:186-191, core :643-706 (run-time-style overloads:
+ *                            do_leader = 1, lib/Matcher.cpp:72-92): every line rewritten with each
+ *                            match replaced by `repl`, at most max_count replacements per line.
+ *                            counts[i] = replacements made in line i (the function's return
+ *                            value); out_offsets[n + 1] = exclusive scan of the rewritten lengths
+ *                            (out_offsets[n] = total bytes); line i's result is
+ *                            out[out_offsets[i] .. out_offsets[i + 1]).  out may be NULL (sizes
+ *                            only); with out != NULL every line that fits entirely below out_cap
+ *                            is written - check out_offsets[n] <= out_cap, else call again with
+ *                            a buffer of out_offsets[n] bytes. */
+int redgpu_replace_batch(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                         const uint64_t *offsets, uint64_t stride, uint64_t n, const uint8_t *repl,
+                         uint64_t repl_len, uint64_t max_count, uint64_t *counts,
+                         uint64_t *out_offsets, uint8_t *out, uint64_t out_cap);
+
 /* ---- the same verbs over DEVICE-resident buffers, asynchronous on `stream` ---------------
  * data/offsets/result/start/end are device pointers on the handle's device; `stream` is a
  * hipStream_t (NULL = the default stream).  Nothing is copied or synchronised; the only
@@ -226,6 +242,13 @@ int redgpu_match_all_batch_dev(const redgpu_dfa *dfa, int do_leader, const uint8
 int redgpu_advance_batch_dev(const redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,
                              uint64_t stride, uint64_t n, uint32_t *state, int32_t *result,
                              void *stream);
+
+/* repl is device memory too */
+int redgpu_replace_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                             const uint64_t *offsets, uint64_t stride, uint64_t n,
+                             const uint8_t *repl, uint64_t repl_len, uint64_t max_count,
+                             uint64_t *counts, uint64_t *out_offsets, uint8_t *out,
+                             uint64_t out_cap, void *stream);
 
 /* The step BEFORE the path, on the device (the reference does it on the host:
  * lib/Util.cpp:109-130 sampleLines, and every tool that walks a text blob line by line): finds

@@ -275,6 +275,38 @@ inline size_t collect(const Executable &exec, std::string_view sv, std::vector<O
       exec, sv, out);
 }
 
+// replace(exec, sv, repl, out, max, style): include/Matcher.h:119-124, lib/Matcher.cpp:72-92
+// (run-time style, doLeader = true); the templates of Matcher.h:186-211 below it
+namespace detail {
+inline size_t replaceOne(const Executable &exec, std::string_view sv, std::string_view repl,
+                         std::string &out, size_t max, int style, int doLeader) {
+  const uint64_t off[2] = {0, sv.size()};
+  uint64_t cnt = 0, ooff[2] = {0, 0};
+  out.assign(sv.size() + 64, '\0');
+  for (int pass = 0; pass < 2; ++pass) {
+    throwOnError(redgpu_replace_batch(exec.handle(), style, doLeader,
+                                      reinterpret_cast<const Byte *>(sv.data()), off, 0, 1,
+                                      reinterpret_cast<const Byte *>(repl.data()), repl.size(), max,
+                                      &cnt, ooff, reinterpret_cast<Byte *>(out.data()),
+                                      out.size()));
+    if (ooff[1] <= out.size()) break;
+    out.assign(size_t(ooff[1]), '\0');
+  }
+  out.resize(size_t(ooff[1]));
+  return size_t(cnt);
+}
+} // namespace detail
+
+inline size_t replace(const Executable &exec, std::string_view sv, std::string_view repl,
+                      std::string &out, size_t max, Style style) {
+  return detail::replaceOne(exec, sv, repl, out, max, style, 1);
+}
+template <Style style, bool doLeader>
+size_t replace(const Executable &exec, std::string_view sv, std::string_view repl, std::string &out,
+               size_t max) {
+  return detail::replaceOne(exec, sv, repl, out, max, style, doLeader);
+}
+
 // StatefulMatcher: include/Matcher.h:770-792.  advance(Byte) as in the reference, plus
 // advance(ptr, len) for a whole chunk per launch.  exec must outlive this object.
 class StatefulMatcher {

@@ -10,10 +10,10 @@ from .matcher import (Executable, Style, RedExcept, RedExceptApi, RedExceptExec,
                       RedExceptLimit, RedExceptHip, check, check_batch, check_header, match,
                       match_batch, scan, scan_batch, search, search_batch, collect,
                       collect_batch, match_all, match_all_batch, advance_batch,
-                      StatefulMatcher, STATE_INITIAL, split_lines, last_kernel, styInstant, styFirst,
+                      StatefulMatcher, STATE_INITIAL, split_lines, replace, replace_batch, last_kernel, styInstant, styFirst,
                       styTangent, styLast, styFull)
 
 __all__ = ["Executable", "Style", "check", "match", "scan", "check_batch", "match_batch",
            "scan_batch", "search", "search_batch", "collect", "collect_batch", "check_header",
            "match_all", "match_all_batch", "advance_batch", "StatefulMatcher", "STATE_INITIAL",
-           "split_lines", "last_kernel"]
+           "split_lines", "replace", "replace_batch", "last_kernel"]

@@ -118,6 +118,12 @@ def lib() -> C.CDLL:
         l.redgpu_dfa_tune.argtypes = [vp, vp, vp, u64, u64]
         l.redgpu_dfa_tune_dev.restype = C.c_int
         l.redgpu_dfa_tune_dev.argtypes = [vp, vp, vp, u64, u64, vp]
+        l.redgpu_replace_batch.restype = C.c_int
+        l.redgpu_replace_batch.argtypes = [vp, i32, i32, vp, vp, u64, u64, vp, u64, u64, vp, vp,
+                                           vp, u64]
+        l.redgpu_replace_batch_dev.restype = C.c_int
+        l.redgpu_replace_batch_dev.argtypes = [vp, i32, i32, vp, vp, u64, u64, vp, u64, u64, vp,
+                                               vp, vp, u64, vp]
         l.redgpu_split_lines.restype = C.c_int
         l.redgpu_split_lines.argtypes = [vp, vp, u64, C.c_uint8, vp, u64, vp]
         l.redgpu_split_lines_dev.restype = C.c_int

@@ -75,6 +75,14 @@ hipError_t launchAdvance(const DevDfa &dfa, const Batch &b, uint32_t *state, con
 hipError_t launchVisits(const DevDfa &dfa, const Batch &b, uint32_t *hist, const LaunchCfg &cfg,
                         hipStream_t stream);
 
+// replaceCore per line (include/Matcher.h:643-706): counts[n], outOffsets[n + 1] (exclusive scan
+// of the rewritten lengths, [n] = total) always; with out != nullptr also the rewritten bytes of
+// every line that fits below outCap.  repl is device memory.
+hipError_t launchReplace(const DevDfa &dfa, const Batch &b, int style, int doLeader,
+                         const uint8_t *repl, uint64_t replLen, uint64_t max, uint64_t *counts,
+                         uint64_t *outOffsets, uint8_t *out, uint64_t outCap,
+                         const LaunchCfg &cfg, hipStream_t stream);
+
 // Line splitting (lib/Util.cpp:109-130's rule): offsets[0] = 0, offsets[k+1] = position after the
 // k-th delimiter, for k < cap; *nLines = delimiters found.  counts: uint32[splitChunks(len)],
 // bases: uint64[splitChunks(len)] scratch, both device memory.

@@ -741,6 +741,156 @@ k_advance(DevDfa d, Batch b, uint32_t *state) {
   }
 }
 
+// include/Matcher.h:643-706 replaceCore.  out == nullptr: only count and measure.
+// Returns the number of replacements; outLen = length of the rewritten line.
+template <class T>
+__device__ uint64_t replaceLane(const T &tab, const LaneCtx &c, const uint8_t *p, uint64_t n,
+                                int style, bool lead, const uint8_t *repl, uint64_t replLen,
+                                uint64_t max, uint8_t *out, uint64_t &outLen) {
+  uint64_t cnt = 0, w = 0, in = 0;
+  while (in < n) {
+    if (cnt >= max) {
+      if (out)
+        for (uint64_t k = in; k < n; ++k) out[w + (k - in)] = p[k];
+      w += n - in;
+      break;
+    }
+    uint64_t found = ~0ull;
+    if (!lead || lookingAt(c, p, in, n)) {
+      uint32_t s = c.init;
+      int32_t prev = 0;
+      for (uint64_t q = in; q < n; ++q) {
+        s = tab.next(s, p[q]);
+        if (s >= c.firstAccept) {
+          const int32_t r = c.res[s];
+          if (style == kStyFirst) {
+            if (prev && r != prev) break;
+            prev = r;
+          }
+          found = q;
+          if (style == kStyInstant) break;
+        } else {
+          if (style == kStyFull) found = ~0ull;
+          if (((style == kStyFirst || style == kStyTangent) && found != ~0ull) ||
+              s < c.nPureDead)
+            break;
+        }
+      }
+    }
+    if (found != ~0ull) {
+      if (out)
+        for (uint64_t k = 0; k < replLen; ++k) out[w + k] = repl[k];
+      w += replLen;
+      in = found + 1;
+      ++cnt;
+    } else {
+      if (out) out[w] = p[in];
+      ++w;
+      ++in;
+    }
+  }
+  outLen = w;
+  return cnt;
+}
+
+// pass 1 (out == nullptr): counts[line], outLens[line].  pass 2: writes line i's rewritten
+// bytes at out + outOffsets[i] when outOffsets[i + 1] <= outCap.
+template <int KIND, int kThreads>
+__global__ void __launch_bounds__(kThreads)
+k_replace(DevDfa d, Batch b, int style, int lead, const uint8_t *repl, uint64_t replLen,
+          uint64_t max, uint64_t *counts, uint64_t *outLens, const uint64_t *outOffsets,
+          uint8_t *out, uint64_t outCap) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  uint8_t *eq = lds;
+  uint8_t *leader = lds + 256;
+  const Tab<KIND> tab = stageTab<KIND, kThreads>(d, lds);
+  LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
+            d.leaderLen};
+  const uint64_t step = uint64_t(gridDim.x) * kThreads;
+  for (uint64_t line = uint64_t(blockIdx.x) * kThreads + threadIdx.x; line < b.n; line += step) {
+    const uint8_t *p;
+    uint64_t n;
+    if (b.offsets) {
+      const uint64_t o = b.offsets[line];
+      p = b.data + o;
+      n = b.offsets[line + 1] - o;
+      n = n >= b.stride ? n - b.stride : 0;  // stride = trailing bytes to drop (ragged)
+    } else {
+      p = b.data + line * b.stride;
+      n = b.stride;
+    }
+    uint64_t len = 0;
+    if (!out) {
+      counts[line] = replaceLane(tab, c, p, n, style, lead != 0, repl, replLen, max, nullptr, len);
+      outLens[line] = len;
+    } else if (outOffsets[line + 1] <= outCap) {
+      replaceLane(tab, c, p, n, style, lead != 0, repl, replLen, max, out + outOffsets[line], len);
+    }
+  }
+}
+
+// exclusive scan of lens[n] into offs[n + 1] (offs[n] = total): per-1024 partial sums, one
+// workgroup over the partials, then the fill
+__global__ void __launch_bounds__(256)
+k_scan_partials(const uint64_t *lens, uint64_t n, uint64_t *partials) {
+  __shared__ uint64_t ws[4];
+  const uint64_t base = uint64_t(blockIdx.x) * 1024;
+  uint64_t v = 0;
+  for (uint32_t k = 0; k < 4; ++k) {
+    const uint64_t i = base + k * 256 + threadIdx.x;
+    v += i < n ? lens[i] : 0;
+  }
+  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ void __launch_bounds__(1024)
+k_scan_tops(uint64_t *partials, uint64_t nPart) {
+  __shared__ uint64_t part[1024];
+  const uint64_t per = (nPart + 1023) / 1024;
+  const uint64_t lo = uint64_t(threadIdx.x) * per;
+  const uint64_t hi = lo + per < nPart ? lo + per : nPart;
+  uint64_t sum = 0;
+  for (uint64_t i = lo; i < hi; ++i) sum += partials[i];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t run = 0;
+    for (int i = 0; i < 1024; ++i) { const uint64_t v = part[i]; part[i] = run; run += v; }
+  }
+  __syncthreads();
+  uint64_t run = part[threadIdx.x];
+  for (uint64_t i = lo; i < hi; ++i) { const uint64_t v = partials[i]; partials[i] = run; run += v; }
+}
+
+__global__ void __launch_bounds__(256)
+k_scan_fill(const uint64_t *lens, uint64_t n, const uint64_t *partials, uint64_t *offs) {
+  // one wave per 256 elements would do; keep it simple: thread 0 of each 64-lane group walks
+  // its 64 elements after a wave-level prefix
+  const uint64_t base = uint64_t(blockIdx.x) * 1024;
+  __shared__ uint64_t ws[4];
+  uint64_t carry = partials[blockIdx.x];
+  for (uint32_t k = 0; k < 4; ++k) {
+    const uint64_t i = base + k * 256 + threadIdx.x;
+    const uint64_t v = i < n ? lens[i] : 0;
+    uint64_t incl = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint64_t u = __shfl_up(incl, o);
+      if ((threadIdx.x & 63) >= uint32_t(o)) incl += u;
+    }
+    if ((threadIdx.x & 63) == 63) ws[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint64_t wb = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) wb += ws[w];
+    if (i < n) offs[i] = carry + wb + incl - v;
+    if (i + 1 == n) offs[n] = carry + wb + incl;
+    carry += ws[0] + ws[1] + ws[2] + ws[3];
+    __syncthreads();
+  }
+}
+
 // Visit histogram for redgpu_dfa_tune: the anchored walk of match<styLast,false> over every
 // line of a SAMPLE, hist[state] += 1 per byte consumed.  A profiling pass, not a hot path:
 // plain global atomics.
@@ -1098,6 +1248,65 @@ hipError_t launchMatchAll(const DevDfa &d, const Batch &b, uint64_t cap, uint64_
 #define MA_CALL(K) launchMatchAllK<K>(d, b, cap, counts, lead, cfg, stream)
   REDGPU_KIND_SWITCH(MA_CALL)
 #undef MA_CALL
+}
+
+template <int KIND>
+hipError_t launchReplaceK(const DevDfa &d, const Batch &b, int style, int lead, const uint8_t *repl,
+                          uint64_t replLen, uint64_t max, uint64_t *counts, uint64_t *outLens,
+                          const uint64_t *outOffsets, uint8_t *out, uint64_t outCap,
+                          const LaunchCfg &cfg, hipStream_t stream) {
+  constexpr bool kLds = Tab<KIND>::kInLds || KIND == REDGPU_TAB_HOT_ROWS;
+  constexpr int kThreads = kLds ? 1024 : 256;
+  const size_t ldsBytes = 512 + ldsTableBytes<KIND>(d);
+  hipError_t e = setLds(k_replace<KIND, kThreads>, ldsBytes);
+  if (e != hipSuccess) return e;
+  uint64_t blocks = (b.n + kThreads - 1) / kThreads;
+  const uint64_t perCu = kLds ? (ldsBytes <= 80 * 1024 ? 2 : 1) : 8;
+  const uint64_t capBlocks = uint64_t(cfg.numCUs) * perCu;
+  if (blocks > capBlocks) blocks = capBlocks;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL((k_replace<KIND, kThreads>), dim3(uint32_t(blocks)), dim3(kThreads), ldsBytes,
+                     stream, d, b, style, lead, repl, replLen, max, counts, outLens, outOffsets,
+                     out, outCap);
+  return hipGetLastError();
+}
+
+static hipError_t launchReplacePass(const DevDfa &d, const Batch &b, int style, int lead,
+                                    const uint8_t *repl, uint64_t replLen, uint64_t max,
+                                    uint64_t *counts, uint64_t *outLens,
+                                    const uint64_t *outOffsets, uint8_t *out, uint64_t outCap,
+                                    const LaunchCfg &cfg, hipStream_t stream) {
+#define RP_CALL(K) launchReplaceK<K>(d, b, style, lead, repl, replLen, max, counts, outLens, \
+                                     outOffsets, out, outCap, cfg, stream)
+  REDGPU_KIND_SWITCH(RP_CALL)
+#undef RP_CALL
+}
+
+hipError_t launchReplace(const DevDfa &d, const Batch &b, int style, int doLeader,
+                         const uint8_t *repl, uint64_t replLen, uint64_t max, uint64_t *counts,
+                         uint64_t *outOffsets, uint8_t *out, uint64_t outCap,
+                         const LaunchCfg &cfg, hipStream_t stream) {
+  if (b.n == 0) return hipSuccess;
+  const int lead = doLeader && d.leaderLen > 0;
+  // scratch: lens u64[n] + partials u64[ceil(n / 1024)]
+  const uint64_t nPart = (b.n + 1023) / 1024;
+  void *scratch = nullptr;
+  hipError_t e = raggedScratch(stream, size_t(b.n + nPart) * 8 + 64, &scratch);
+  if (e != hipSuccess) return e;
+  uint64_t *lens = static_cast<uint64_t *>(scratch);
+  uint64_t *partials = lens + b.n;
+  e = launchReplacePass(d, b, style, lead, repl, replLen, max, counts, lens, nullptr, nullptr, 0,
+                        cfg, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_scan_partials, dim3(uint32_t(nPart)), dim3(256), 0, stream, lens, b.n,
+                     partials);
+  hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, stream, partials, nPart);
+  hipLaunchKernelGGL(k_scan_fill, dim3(uint32_t(nPart)), dim3(256), 0, stream, lens, b.n, partials,
+                     outOffsets);
+  e = hipGetLastError();
+  if (e != hipSuccess || !out) return e;
+  return launchReplacePass(d, b, style, lead, repl, replLen, max, counts, lens, outOffsets, out,
+                           outCap, cfg, stream);
 }
 
 uint64_t splitChunks(uint64_t len) { return (len + kSplitChunk - 1) / kSplitChunk; }

@@ -454,6 +454,95 @@ static int listHost(const redgpu_dfa *dfa, int listVerb, const uint8_t *data,
   return REDGPU_OK;
 }
 
+int redgpu_replace_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                             const uint64_t *offsets, uint64_t stride, uint64_t n,
+                             const uint8_t *repl, uint64_t repl_len, uint64_t max_count,
+                             uint64_t *counts, uint64_t *out_offsets, uint8_t *out,
+                             uint64_t out_cap, void *stream) {
+  if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
+  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (int rc = checkStyle(style)) return rc;
+  if (n == 0) return REDGPU_OK;
+  if (!counts || !out_offsets) return fail(REDGPU_EAPI, "null output buffer");
+  if (!data && (offsets || stride)) return fail(REDGPU_EAPI, "null data buffer");
+  if (repl_len && !repl) return fail(REDGPU_EAPI, "null replacement");
+  if (offsets && stride > 16) return fail(REDGPU_EAPI, "with offsets, stride is the number of "
+                                                       "trailing bytes to drop per line (0..16)");
+  DeviceScope scope(dfa->device);
+  if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  Batch b{data, offsets, stride, n, nullptr, nullptr, nullptr};
+  LaunchCfg cfg{dfa->numCUs, 0};
+  hipError_t e = launchReplace(dfa->dev, b, style, do_leader ? 1 : 0, repl, repl_len, max_count,
+                               counts, out_offsets, out, out_cap, cfg,
+                               static_cast<hipStream_t>(stream));
+  tlsKernel = "k_replace";
+  if (e != hipSuccess) return failHip(e, "kernel launch");
+  return REDGPU_OK;
+}
+
+int redgpu_replace_batch(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                         const uint64_t *offsets, uint64_t stride, uint64_t n, const uint8_t *repl,
+                         uint64_t repl_len, uint64_t max_count, uint64_t *counts,
+                         uint64_t *out_offsets, uint8_t *out, uint64_t out_cap) {
+  if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
+  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (int rc = checkStyle(style)) return rc;
+  if (n == 0) return REDGPU_OK;
+  if (!counts || !out_offsets) return fail(REDGPU_EAPI, "null output buffer");
+  const uint64_t total = offsets ? offsets[n] : stride * n;
+  if (offsets) {
+    for (uint64_t i = 0; i < n; ++i)
+      if (offsets[i] > offsets[i + 1]) return fail(REDGPU_EAPI, "offsets not monotonic");
+  }
+  if (total && !data) return fail(REDGPU_EAPI, "null data buffer");
+  if (repl_len && !repl) return fail(REDGPU_EAPI, "null replacement");
+  DeviceScope scope(dfa->device);
+  if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  uint8_t *dData = nullptr, *dRepl = nullptr, *dOut = nullptr;
+  uint64_t *dOff = nullptr, *dCnt = nullptr, *dOutOff = nullptr;
+  auto cleanup = [&]() {
+    for (void *q : {(void *)dData, (void *)dRepl, (void *)dOut, (void *)dOff, (void *)dCnt,
+                    (void *)dOutOff})
+      if (q) (void)hipFree(q);
+  };
+  int rc = REDGPU_OK;
+#define RP_TRY(expr, what)                                                    \
+  do {                                                                        \
+    hipError_t e_ = (expr);                                                   \
+    if (e_ != hipSuccess) { rc = failHip(e_, what); cleanup(); return rc; }   \
+  } while (0)
+  RP_TRY(hipMalloc(reinterpret_cast<void **>(&dData), total + 16), "hipMalloc data");
+  RP_TRY(hipMalloc(reinterpret_cast<void **>(&dRepl), repl_len + 16), "hipMalloc repl");
+  RP_TRY(hipMalloc(reinterpret_cast<void **>(&dCnt), n * 8), "hipMalloc counts");
+  RP_TRY(hipMalloc(reinterpret_cast<void **>(&dOutOff), (n + 1) * 8), "hipMalloc out offsets");
+  if (out && out_cap) RP_TRY(hipMalloc(reinterpret_cast<void **>(&dOut), out_cap), "hipMalloc out");
+  if (offsets) {
+    RP_TRY(hipMalloc(reinterpret_cast<void **>(&dOff), (n + 1) * 8), "hipMalloc offsets");
+    RP_TRY(hipMemcpy(dOff, offsets, (n + 1) * 8, hipMemcpyHostToDevice), "copy offsets");
+  }
+  if (total) RP_TRY(hipMemcpy(dData, data, total, hipMemcpyHostToDevice), "copy data");
+  if (repl_len) RP_TRY(hipMemcpy(dRepl, repl, repl_len, hipMemcpyHostToDevice), "copy repl");
+  rc = redgpu_replace_batch_dev(dfa, style, do_leader, dData, dOff, stride, n, dRepl, repl_len,
+                                max_count, dCnt, dOutOff, dOut, dOut ? out_cap : 0, nullptr);
+  if (rc != REDGPU_OK) { cleanup(); return rc; }
+  RP_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  RP_TRY(hipMemcpy(counts, dCnt, n * 8, hipMemcpyDeviceToHost), "copy counts");
+  RP_TRY(hipMemcpy(out_offsets, dOutOff, (n + 1) * 8, hipMemcpyDeviceToHost), "copy out offsets");
+  if (dOut) {
+    // the lines that fit are a prefix (offsets are monotone): copy up to the last one that does
+    uint64_t lo = 0, hi = n;  // largest k with out_offsets[k] <= out_cap
+    while (lo < hi) {
+      const uint64_t mid = (lo + hi + 1) / 2;
+      if (out_offsets[mid] <= out_cap) lo = mid; else hi = mid - 1;
+    }
+    if (out_offsets[lo])
+      RP_TRY(hipMemcpy(out, dOut, out_offsets[lo], hipMemcpyDeviceToHost), "copy out");
+  }
+#undef RP_TRY
+  cleanup();
+  return REDGPU_OK;
+}
+
 int redgpu_split_lines_dev(const redgpu_dfa *dfa, const uint8_t *data, uint64_t len, uint8_t delim,
                            uint64_t *offsets, uint64_t cap, uint64_t *n_lines, void *stream) {
   if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");

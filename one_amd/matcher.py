@@ -358,6 +358,44 @@ def advance_batch(exe, data, state, *, offsets=None, stride=0, n=None, out=None)
     return res
 
 
+def replace_batch(exe, data, repl: bytes, style, do_leader=True, max_count=(1 << 62), *,
+                  offsets=None, stride=0, n=None):
+    """replace<style,doLeader> (include/Matcher.h:643-706) over every line: each match replaced
+    by `repl`, at most max_count per line.  Host arrays in and out:
+    (counts uint64[n], out_offsets uint64[n+1], out uint8[out_offsets[n]])."""
+    a = _host_u8(data)
+    if offsets is not None:
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        stride = int(stride or 0)  # with offsets: trailing bytes to drop per line
+    elif n is None:
+        n = a.size // stride if stride else 0
+    counts = np.zeros(n, dtype=np.uint64)
+    ooff = np.zeros(n + 1, dtype=np.uint64)
+    r = np.frombuffer(bytes(repl), dtype=np.uint8)
+    f = _lib.lib().redgpu_replace_batch
+    args = (exe._h, int(style), 1 if do_leader else 0, a.ctypes.data if a.size else None,
+            offsets.ctypes.data if offsets is not None else None, stride, n,
+            r.ctypes.data if r.size else None, r.size, int(max_count), counts.ctypes.data,
+            ooff.ctypes.data)
+    # first guess: output about as long as the input; retry once with the exact size
+    cap = int(a.size + 64)
+    out = np.zeros(cap, dtype=np.uint8)
+    _check(f(*args, out.ctypes.data, cap))
+    total = int(ooff[n]) if n else 0
+    if total > cap:
+        out = np.zeros(total, dtype=np.uint8)
+        _check(f(*args, out.ctypes.data, total))
+    return counts, ooff, out[:total]
+
+
+def replace(exe, text: bytes, repl: bytes, max_count, style, do_leader=True):
+    """replace(exec, text, repl, out, max, style) on one text -> (count, rewritten bytes)."""
+    counts, ooff, out = replace_batch(exe, text, repl, style, do_leader, max_count,
+                                      offsets=[0, len(text)])
+    return int(counts[0]), out.tobytes()
+
+
 def split_lines(exe, data, delim=b"\n", cap=None):
     """redgpu_split_lines: offsets of the delimiter-terminated lines of a raw text buffer, found
     on the device (the rule of lib/Util.cpp:109-130: bytes after the last delimiter are not a

@@ -86,6 +86,10 @@ def _orc():
         lib.oracle_collect_batch.argtypes = [C.POINTER(_Dfa), C.c_void_p, C.c_void_p, C.c_uint64,
                                              C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.oracle_replace.restype = C.c_uint64
+        lib.oracle_replace.argtypes = [C.POINTER(_Dfa), C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p,
+                                       C.c_uint64, C.POINTER(C.c_uint64)]
         lib.oracle_match_all.restype = C.c_uint64
         lib.oracle_match_all.argtypes = [C.POINTER(_Dfa), C.c_void_p, C.c_size_t, C.c_int,
                                          C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -237,6 +241,16 @@ class CpuOracle(_Batchable):
         return counts, res, st, en
 
 
+    def replace(self, text: bytes, repl: bytes, style, do_leader=True, max_count=(1 << 62)):
+        """replace<style,doLeader> (Matcher.h:643-706) -> (count, result bytes)"""
+        cap = len(text) + (len(text) + 1) * len(repl) + 8
+        out = np.zeros(cap, dtype=np.uint8)
+        ol = C.c_uint64(0)
+        k = _orc().oracle_replace(C.byref(self._d), text, len(text), _style(style),
+                                  int(bool(do_leader)), repl, len(repl), int(max_count),
+                                  out.ctypes.data, cap, C.byref(ol))
+        return int(k), out[:ol.value].tobytes()
+
     def match_all(self, text: bytes, do_leader=True, cap: int = 64):
         """matchAll (Matcher.h:711-766): list of (result, start, end), and the number found."""
         res = np.zeros(cap, dtype=np.int32)
@@ -353,6 +367,10 @@ def _ref():
         lib.ref_collect.restype = C.c_uint64
         lib.ref_collect.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint64,
                                     C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ref_replace.restype = C.c_uint64
+        lib.ref_replace.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p, C.c_uint64,
+                                    C.POINTER(C.c_uint64)]
         lib.ref_match_all.restype = C.c_uint64
         lib.ref_match_all.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p,
                                       C.c_void_p, C.c_void_p]
@@ -462,6 +480,16 @@ class Reference(_Batchable):
 
     def search(self, text: bytes, style, do_leader):
         return self._oc(_ref().ref_search, text, style, do_leader)
+
+    def replace(self, text: bytes, repl: bytes, style, do_leader=True, max_count=(1 << 62)):
+        """The reference's replace<style,doLeader> -> (count, result bytes)"""
+        cap = len(text) + (len(text) + 1) * len(repl) + 8
+        out = np.zeros(cap, dtype=np.uint8)
+        ol = C.c_uint64(0)
+        k = _ref().ref_replace(self._h, text, len(text), _style(style), int(bool(do_leader)),
+                               repl, len(repl), int(max_count), out.ctypes.data, cap,
+                               C.byref(ol))
+        return int(k), out[:ol.value].tobytes()
 
     def match_all(self, text: bytes, cap: int = 64):
         """The reference's matchAll(exec, sv, out) (always doLeader = true)."""

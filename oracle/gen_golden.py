@@ -474,6 +474,7 @@ def gen_matchall_stateful():
     # blobs for the C++ mirror test (tests/cpp/matcher_cabi_test.cpp)
     for name, pats in (("set5", SET5), ("loose2", [("a+", 1, LS), ("b+", 2, LS)]),
                        ("ale", [("ale+", 1, 0), ("ale*x", 2, 0)]),
+                       ("num3defg", [("[0-9]+", 1, 0), ("[0-9]+d", 2, 0), ("[0-9]+defg", 3, 0)]),
                        ("newyork4", [("new york", 1, 0), ("new", 2, 0), ("york", 3, 0),
                                      ("[0-9]+", 4, 0)])):
         with open(os.path.join(GOLD, "dfas", name + ".reda"), "wb") as f:
@@ -538,11 +539,79 @@ def gen_matchall_stateful():
           (len(kats), len(skat), len(ins), len(sets)))
 
 
+def gen_replace():
+    """replace (include/Matcher.h:643-706): the known answers of test/matcher.cpp:648-691 through
+    the real reference in every format, + reference outputs on the mixed input set for every
+    style x doLeader, two replacement strings and two max counts."""
+    kats = []
+    rows1 = [("fooac", "bar", 9999, "last", 1, "foobar"), ("fooacz", "bar", 9999, "last", 1, "foobarz"),
+             ("xacyabbcz", ",", 9999, "tangent", 2, "x,y,z")]
+    rows2 = [("#123defg!", "xyz", 1, "instant", 1, "#xyz23defg!"),
+             ("#123defg!", "xyz", 9999, "instant", 3, "#xyzxyzxyzdefg!"),
+             ("#123defg!", "xyz", 9999, "first", 1, "#xyzdefg!"),
+             ("#123defg!", "xyz", 9999, "tangent", 1, "#xyzefg!"),
+             ("#123defg!", "xyz", 9999, "last", 1, "#xyz!"),
+             ("#123defg!", "xyz", 9999, "full", 0, "#123defg!"),
+             ("#123defg", "xyz", 9999, "full", 1, "#xyz")]
+    for src, pats, rows in (("test/matcher.cpp:648-664", [("ab*c", 1, 0)], rows1),
+                            ("test/matcher.cpp:667-691",
+                             [("[0-9]+", 1, 0), ("[0-9]+d", 2, 0), ("[0-9]+defg", 3, 0)], rows2)):
+        for fmt, blob in compile_all_formats(pats).items():
+            if isinstance(blob, tuple):
+                continue
+            ref = O.Reference(blob)
+            for text, repl, mx, sty, cnt, exp in rows:
+                got = ref.replace(text.encode(), repl.encode(), sty, True, mx)
+                assert got == (cnt, exp.encode()), (src, fmt, text, sty, got)
+                kats.append(dict(src=src, fmt=fmt, reda=b64(blob), text=text, repl=repl, max=mx,
+                                 style=sty, count=cnt, expect=exp))
+    with open(os.path.join(GOLD, "replace_kat.json"), "w") as f:
+        json.dump(kats, f)
+    rng = np.random.default_rng(0x4E91)
+    ins = inputs_for("replace", rng)[:420]
+    ins += [b"fooac", b"xacyabbcz", b"#123defg!", b"#123defg", b"", b"0", b"00", b"a1b22c333"]
+    data = np.frombuffer(b"".join(ins), dtype=np.uint8)
+    offsets = np.zeros(len(ins) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(x) for x in ins])
+    dfas = config_dfas()
+    sets = dict(num3=dfas["num3"], newyork=dfas["newyork"], err=dfas["err"], uri=dfas["uri"],
+                abc=O.ref_compile([("ab*c", 1, 0)]))
+    arrays = dict(data=data, offsets=offsets)
+    cases = [(b"<>", 1 << 62), (b"", 2), (b"a much longer replacement", 1)]
+    for name, b in sets.items():
+        ref, cpu = O.Reference(b), O.CpuOracle(b)
+        arrays[name + "_blob"] = np.frombuffer(b, dtype=np.uint8)
+        for ci, (repl, mx) in enumerate(cases):
+            for si, sty in enumerate(STY, start=1):
+                for lead in (0, 1):
+                    counts = np.zeros(len(ins), dtype=np.uint64)
+                    outs = []
+                    for i, t in enumerate(ins):
+                        k, o = ref.replace(t, repl, sty, lead, mx)
+                        assert (k, o) == cpu.replace(t, repl, sty, lead, mx), (name, sty, lead, t)
+                        counts[i] = k
+                        outs.append(o)
+                    ooff = np.zeros(len(ins) + 1, dtype=np.uint64)
+                    ooff[1:] = np.cumsum([len(o) for o in outs])
+                    key = "%s_c%d_%d_%d_" % (name, ci, si, lead)
+                    arrays[key + "counts"] = counts.astype(np.uint16)
+                    arrays[key + "ooff"] = ooff.astype(np.uint32)
+                    # the rewritten lines themselves as one FNV-1a-64 per line (the full bytes
+                    # of 150 result sets would be 13 MB); num3's first case is kept whole
+                    arrays[key + "fnv"] = np.array([O.fnv1a64(o) for o in outs], dtype=np.uint64)
+                    if name == "num3" and ci == 0:
+                        arrays[key + "out"] = np.frombuffer(b"".join(outs), dtype=np.uint8)
+    arrays["case_repl"] = np.array([c[0].decode() for c in cases])
+    arrays["case_max"] = np.array([c[1] for c in cases], dtype=np.uint64)
+    np.savez_compressed(os.path.join(GOLD, "replace_vectors.npz"), **arrays)
+    print("replace: %d kats, %d inputs x %d dfas x %d cases" % (len(kats), len(ins), len(sets), len(cases)))
+
+
 def main():
     os.makedirs(os.path.join(GOLD, "dfas"), exist_ok=True)
     only = sys.argv[1:]
     steps = dict(kat=gen_kat, omnibus=gen_omnibus, vectors=gen_vectors, collect=gen_collect,
-                 matchall=gen_matchall_stateful)
+                 matchall=gen_matchall_stateful, replace=gen_replace)
     for name, fn in steps.items():
         if not only or name in only:
             fn()

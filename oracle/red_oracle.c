@@ -457,6 +457,73 @@ void oracle_collect_batch(const oracle_dfa *d, const uint8_t *data, const uint64
   }
 }
 
+/* ---- include/Matcher.h:643-706 replaceCore ---------------------------------------------
+ * Writes at most outCap bytes to out (may be NULL with outCap 0); *outLen = length of the full
+ * result.  Returns the number of replacements. */
+ORA_INLINE uint64_t replace_core(const oracle_dfa *d, const uint8_t *p, size_t n, const int style,
+                                 const int lead, const int V, const uint8_t *repl, size_t replLen,
+                                 uint64_t max, uint8_t *out, uint64_t outCap, uint64_t *outLen) {
+  const uint8_t *stop = p + n;
+  const uint8_t *base = d->base;
+  const uint8_t *equiv = d->equiv;
+  const uint8_t *init = base + d->initialOff;
+  uint64_t cnt = 0, w = 0;
+#define ORA_PUT(ch) do { if (w < outCap) out[w] = (ch); ++w; } while (0)
+  const uint8_t *in = p;
+  while (in < stop) {
+    if (cnt >= max) {
+      for (; in < stop; ++in)
+        ORA_PUT(*in);
+      break;
+    }
+    const uint8_t *found = NULL;
+    if (!lead || looking_at(in, stop, d)) {
+      const uint8_t *st = init;
+      int32_t prevResult = 0;
+      for (const uint8_t *inner = in; inner < stop; ++inner) {
+        st = st_next(base, st, equiv[*inner], V);
+        int32_t result = st_result(st, V);
+        if (ORA_UNLIKELY(result > 0)) {
+          if (style == ORA_STY_FIRST) {
+            if (prevResult && (result != prevResult))
+              break;
+            prevResult = result;
+          }
+          found = inner;
+          if (style == ORA_STY_INSTANT)
+            break;
+        } else {
+          if (style == ORA_STY_FULL)
+            found = NULL;
+          if ((((style == ORA_STY_FIRST) || (style == ORA_STY_TANGENT)) && found) ||
+              st_pure_dead(st, V))
+            break;
+        }
+      }
+    }
+    if (found) {
+      for (size_t k = 0; k < replLen; ++k)
+        ORA_PUT(repl[k]);
+      in = found + 1;
+      ++cnt;
+    } else {
+      ORA_PUT(*in);
+      ++in;
+    }
+  }
+#undef ORA_PUT
+  *outLen = w;
+  return cnt;
+}
+
+uint64_t oracle_replace(const oracle_dfa *d, const uint8_t *p, size_t n, int style, int doLeader,
+                        const uint8_t *repl, size_t replLen, uint64_t max, uint8_t *out,
+                        uint64_t outCap, uint64_t *outLen) {
+#define CALL(S, L, V) return replace_core(d, p, n, S, L, V, repl, replLen, max, out, outCap, outLen)
+  ORA_DISPATCH(CALL)
+#undef CALL
+}
+
 /* ---- include/Matcher.h:711-766 matchAllCore (public entry matchAll, lib/Matcher.cpp:97-102,
  * always <styTangent, doLeader=true>; the style parameter is unused by the core) ---------- */
 ORA_INLINE uint64_t match_all_core(const oracle_dfa *d, const uint8_t *p, size_t n,

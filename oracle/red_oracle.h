@@ -78,6 +78,14 @@ void oracle_collect_batch(const oracle_dfa *d, const uint8_t *data, const uint64
                           uint64_t stride, uint64_t lineLen, uint64_t n, uint64_t cap,
                           uint64_t *counts, int32_t *res, uint64_t *start, uint64_t *end);
 
+/* include/Matcher.h:643-706 replaceCore (public: replace<style,doLeader>, and the run-time-style
+ * overloads with doLeader = 1, lib/Matcher.cpp:72-92).  At most outCap bytes are written;
+ * *outLen = full length of the result; returns the number of replacements, or (uint64_t)-1000
+ * on an unsupported style / format. */
+uint64_t oracle_replace(const oracle_dfa *d, const uint8_t *p, size_t n, int style, int doLeader,
+                        const uint8_t *repl, size_t replLen, uint64_t max, uint8_t *out,
+                        uint64_t outCap, uint64_t *outLen);
+
 /* include/Matcher.h:711-766 matchAllCore; the public matchAll (lib/Matcher.cpp:97-102) runs it
  * with doLeader = 1.  Same cap / count convention as oracle_collect. */
 uint64_t oracle_match_all(const oracle_dfa *d, const uint8_t *p, size_t n, int doLeader,

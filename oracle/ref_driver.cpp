@@ -242,6 +242,22 @@ uint64_t ref_collect(const void *blob, size_t len, const void *text, size_t n, u
   return out.size();
 }
 
+/* replace<style,doLeader>(exec, ptr, len, repl, out, max) (include/Matcher.h:186-191,643-706) */
+uint64_t ref_replace(void *exv, const void *text, size_t n, int style, int lead, const void *repl,
+                     size_t replLen, uint64_t max, void *out, uint64_t outCap, uint64_t *outLen) {
+  const Executable &ex = *static_cast<Executable *>(exv);
+  std::string_view rv(static_cast<const char *>(repl), replLen);
+  std::string o;
+  size_t cnt = 0;
+#define C(S) { cnt = lead ? replace<S, true>(ex, text, n, rv, o, size_t(max))               \
+                          : replace<S, false>(ex, text, n, rv, o, size_t(max)); }
+  STYLE_DISPATCH(C)
+#undef C
+  *outLen = o.size();
+  if (out && outCap) std::memcpy(out, o.data(), o.size() < outCap ? o.size() : outCap);
+  return cnt;
+}
+
 /* matchAll(exec, string_view, vector<Outcome>&) (include/Matcher.h:127, lib/Matcher.cpp:97-102) */
 uint64_t ref_match_all(void *ex, const void *text, size_t n, uint64_t cap, int32_t *res,
                        uint64_t *start, uint64_t *end) {

@@ -104,6 +104,28 @@ int main(int argc, char **argv) {
     EXPECT_EQ(2, sm.advance('x'));
     EXPECT_EQ(2, sm.result());
   }
+  // test/matcher.cpp:667-691 replaceStyles
+  {
+    Executable rex(slurp(dir + "/num3defg.reda"));
+    std::string s;
+    EXPECT_EQ(size_t(1), replace(rex, "#123defg!", "xyz", s, 1, styInstant));
+    EXPECT_EQ(std::string("#xyz23defg!"), s);
+    EXPECT_EQ(size_t(3), replace(rex, "#123defg!", "xyz", s, 9999, styInstant));
+    EXPECT_EQ(std::string("#xyzxyzxyzdefg!"), s);
+    EXPECT_EQ(size_t(1), replace(rex, "#123defg!", "xyz", s, 9999, styFirst));
+    EXPECT_EQ(std::string("#xyzdefg!"), s);
+    EXPECT_EQ(size_t(1), replace(rex, "#123defg!", "xyz", s, 9999, styTangent));
+    EXPECT_EQ(std::string("#xyzefg!"), s);
+    EXPECT_EQ(size_t(1), replace(rex, "#123defg!", "xyz", s, 9999, styLast));
+    EXPECT_EQ(std::string("#xyz!"), s);
+    EXPECT_EQ(size_t(0), replace(rex, "#123defg!", "xyz", s, 9999, styFull));
+    EXPECT_EQ(std::string("#123defg!"), s);
+    EXPECT_EQ(size_t(1), replace(rex, "#123defg", "xyz", s, 9999, styFull));
+    EXPECT_EQ(std::string("#xyz"), s);
+    std::string longRepl(300, 'Z');   // result longer than the first pass's buffer
+    EXPECT_EQ(size_t(3), (replace<styInstant, true>(rex, "#123defg!", longRepl, s, 9999)));
+    EXPECT_EQ(size_t(1 + 900 + 5), s.size());
+  }
   // test/red.cpp:190-221 collect
   {
     Executable rex(slurp(dir + "/newyork4.reda"));

@@ -388,6 +388,54 @@ def test_ragged_length_bucketing_vs_oracle(name):
         assert np.array_equal(one_amd.check_batch(exe, data, 5, 0, offsets=offsets), ef)
 
 
+def test_replace_on_gpu():
+    """replace batch form (include/Matcher.h:643-706) vs the reference's known answers
+    (test/matcher.cpp:648-691, every format) and its outputs in tests/golden/replace_vectors.npz
+    (counts, lengths, FNV-1a-64 per rewritten line; one set byte for byte), every style x
+    doLeader, three (replacement, max) cases, LDS and global table placements; the
+    delimiter-trimmed ragged form; output capacity too small."""
+    import json
+    import os
+    from golden_util import GOLD
+    for k in json.load(open(os.path.join(GOLD, "replace_kat.json"))):
+        exe = one_amd.Executable(unb64(k["reda"]))
+        sty = {"instant": 1, "first": 2, "tangent": 3, "last": 4, "full": 5}[k["style"]]
+        got = one_amd.replace(exe, k["text"].encode(), k["repl"].encode(), k["max"], sty)
+        assert got == (k["count"], k["expect"].encode()), k
+    vec = np.load(os.path.join(GOLD, "replace_vectors.npz"))
+    data, offsets = vec["data"], vec["offsets"]
+    for name in ("num3", "newyork", "err", "uri", "abc"):
+        for kw in ({}, {"force_global": True}):
+            exe = one_amd.Executable(vec[name + "_blob"].tobytes(), **kw)
+            for ci in range(3):
+                repl, mx = str(vec["case_repl"][ci]).encode(), int(vec["case_max"][ci])
+                for si in range(1, 6):
+                    for lead in (0, 1):
+                        key = "%s_c%d_%d_%d_" % (name, ci, si, lead)
+                        counts, ooff, out = one_amd.replace_batch(exe, data, repl, si, lead, mx,
+                                                                  offsets=offsets)
+                        assert np.array_equal(counts, vec[key + "counts"].astype(np.uint64)), key
+                        assert np.array_equal(ooff, vec[key + "ooff"].astype(np.uint64)), key
+                        fnv = np.array([O.fnv1a64(out[int(ooff[i]):int(ooff[i + 1])].tobytes())
+                                        for i in range(len(ooff) - 1)], dtype=np.uint64)
+                        assert np.array_equal(fnv, vec[key + "fnv"]), key
+                        if key + "out" in vec:
+                            assert np.array_equal(out, vec[key + "out"]), key
+    # fixed stride + the oracle; trimmed ragged lines
+    blob = load_dfa("num3")
+    exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
+    n, L = 3000, 48
+    fixed = W.fixed_lines(n, L, 3, alphabet=True)
+    counts, ooff, out = one_amd.replace_batch(exe, fixed, b"#", 4, True, stride=L, n=n)
+    for i in (0, 1, 17, n - 1):
+        k, o = cpu.replace(fixed[i * L:(i + 1) * L].tobytes(), b"#", 4, True)
+        assert int(counts[i]) == k and out[int(ooff[i]):int(ooff[i + 1])].tobytes() == o
+    text = b"a1\nb22 c\n\n333\n"
+    offs, _ = one_amd.split_lines(exe, text)
+    counts, ooff, out = one_amd.replace_batch(exe, text, b"N", 4, True, offsets=offs, stride=1)
+    assert counts.tolist() == [1, 1, 0, 1] and out.tobytes() == b"aNbN cN"
+
+
 def test_edge_cases():
     exe = one_amd.Executable(load_dfa("err"))
     cpu = O.CpuOracle(load_dfa("err"))

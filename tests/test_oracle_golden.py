@@ -168,3 +168,34 @@ def test_split_lines_rule():
         lines = [text[int(offs[k]):int(offs[k + 1]) - 1] for k in range(len(offs) - 1)]
         assert lines == O.split_lines_loop(text)
         assert int(offs[-1]) == (text.rfind(b"\n") + 1)
+
+
+def _fnv_lines(out, ooff):
+    return np.array([O.fnv1a64(out[int(ooff[i]):int(ooff[i + 1])].tobytes())
+                     for i in range(len(ooff) - 1)], dtype=np.uint64)
+
+
+def test_replace_kat_and_vectors():
+    """replace (include/Matcher.h:643-706): the known answers of test/matcher.cpp:648-691 in
+    every format, and the reference's outputs (counts, lengths, FNV-1a-64 per rewritten line)
+    for every style x doLeader x (replacement, max) case on the mixed input set."""
+    import json
+    import os
+    from golden_util import GOLD
+    for k in json.load(open(os.path.join(GOLD, "replace_kat.json"))):
+        cpu = O.CpuOracle(unb64(k["reda"]))
+        got = cpu.replace(k["text"].encode(), k["repl"].encode(), k["style"], True, k["max"])
+        assert got == (k["count"], k["expect"].encode()), k
+    vec = np.load(os.path.join(GOLD, "replace_vectors.npz"))
+    data, offsets = vec["data"], vec["offsets"]
+    ins = [data[int(offsets[i]):int(offsets[i + 1])].tobytes() for i in range(len(offsets) - 1)]
+    for name in ("num3", "abc", "err"):
+        cpu = O.CpuOracle(vec[name + "_blob"].tobytes())
+        for ci in range(3):
+            repl, mx = str(vec["case_repl"][ci]).encode(), int(vec["case_max"][ci])
+            for si in (1, 3, 4, 5):
+                for lead in (0, 1):
+                    key = "%s_c%d_%d_%d_" % (name, ci, si, lead)
+                    res = [cpu.replace(t, repl, si, lead, mx) for t in ins]
+                    assert [r[0] for r in res] == vec[key + "counts"].tolist(), key
+                    assert [O.fnv1a64(r[1]) for r in res] == vec[key + "fnv"].tolist(), key

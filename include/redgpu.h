@@ -99,12 +99,20 @@ typedef struct redgpu_info {
   uint32_t early_death;   /* 1 if the same model sees most walks reach a pure dead end within 16
                              bytes (an anchored DFA on arbitrary text): such DFAs keep the
                              early-exit kernels */
+  uint32_t image_refs;    /* handles currently sharing this handle's device image (the loader
+                             cache: same blob + device + build options -> one repack, one upload) */
 } redgpu_info;
 
 /* Replaces checkHeader (include/Serializer.h:109, lib/Serializer.cpp:270-298): returns
  * REDGPU_OK, or REDGPU_EAPI with *msg (if msg != NULL) pointing at a static string that is
  * byte-for-byte the reference's message. */
 int redgpu_reda_check(const void *reda, size_t len, const char **msg);
+
+/* Loader cache (cf. the reference's load path lib/Serializer.cpp:257-267, which
+ * builds a fresh Executable per call): handles created from byte-identical blobs on the same
+ * device with the same lds_table_max and FORCE_GLOBAL / FORCE_HOT flags share one validated
+ * copy, one repacked image and one set of device tables (redgpu_info.image_refs counts them);
+ * the image is released with its last handle.  redgpu_dfa_tune detaches the tuned handle. */
 
 /* Replaces Executable(gCopyTag, string_view) + Executable::validate
  * (include/Executable.h:37, lib/Executable.cpp:53-70,159-170): validates exactly as

@@ -5,9 +5,11 @@
 
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -17,18 +19,38 @@
 
 using namespace redgpu;
 
-struct redgpu_dfa {
+// What is expensive to make - the validated blob copy, the repacked image and its device
+// allocations - is immutable once built and shared between handles created from the same blob
+// with the same options on the same device (the loader cache below).
+struct SharedImage {
   std::vector<uint8_t> blob;  // our own copy (Executable(gCopyTag,..) semantics)
   DfaImage img;
   int device = REDGPU_DEVICE_NONE;
-  int numCUs = 0;
-  uint32_t flags = 0;
+  uint32_t buildFlags = 0;    // the flags / LDS budget the image was built with (cache key)
   uint32_t ldsTableMax = 0;
-  // device allocations
   void *dTable = nullptr;
   void *dResult = nullptr;
   void *dEquivLeader = nullptr;
   DevDfa dev{};
+  ~SharedImage();
+};
+
+SharedImage::~SharedImage() {
+  if (device < 0) return;
+  int prev = -1;
+  const bool sw = hipGetDevice(&prev) == hipSuccess && prev != device &&
+                  hipSetDevice(device) == hipSuccess;
+  if (dTable) (void)hipFree(dTable);
+  if (dResult) (void)hipFree(dResult);
+  if (dEquivLeader) (void)hipFree(dEquivLeader);
+  if (sw) (void)hipSetDevice(prev);
+}
+
+struct redgpu_dfa {
+  std::shared_ptr<SharedImage> im;
+  int numCUs = 0;
+  uint32_t flags = 0;
+  uint32_t ldsTableMax = 0;
 };
 
 namespace {
@@ -79,7 +101,7 @@ int runDev(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint8
            const uint64_t *offsets, uint64_t stride, uint64_t n, int32_t *result,
            uint64_t *start, uint64_t *end, hipStream_t stream) {
   if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
-  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (dfa->im->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
   if (int rc = checkStyle(style)) return rc;
   if (n == 0) return REDGPU_OK;
   if (!result) return fail(REDGPU_EAPI, "null result buffer");
@@ -87,13 +109,13 @@ int runDev(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint8
   if (!offsets && stride >= (1ull << 40)) return fail(REDGPU_ELIMIT, "stride too large");
   if (offsets && stride > 16) return fail(REDGPU_EAPI, "with offsets, stride is the number of "
                                                        "trailing bytes to drop per line (0..16)");
-  DeviceScope scope(dfa->device);
+  DeviceScope scope(dfa->im->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   Batch b{data, offsets, stride, n, result, start, end};
   LaunchCfg cfg{dfa->numCUs, (dfa->flags & REDGPU_F_FORCE_GENERIC) ? 1 : 0,
                 (dfa->flags & REDGPU_F_NO_BUCKETING) ? 1 : 0};
   const char *name = "";
-  hipError_t e = launchBatch(dfa->dev, b, verb, style, doLeader ? 1 : 0, cfg, stream, &name);
+  hipError_t e = launchBatch(dfa->im->dev, b, verb, style, doLeader ? 1 : 0, cfg, stream, &name);
   tlsKernel = name;
   if (e != hipSuccess) return failHip(e, "kernel launch");
   return REDGPU_OK;
@@ -104,7 +126,7 @@ int runHost(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint
             const uint64_t *offsets, uint64_t stride, uint64_t n, int32_t *result,
             uint64_t *start, uint64_t *end) {
   if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
-  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (dfa->im->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
   if (int rc = checkStyle(style)) return rc;
   if (n == 0) return REDGPU_OK;
   if (!result) return fail(REDGPU_EAPI, "null result buffer");
@@ -114,7 +136,7 @@ int runHost(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint
       if (offsets[i] > offsets[i + 1]) return fail(REDGPU_EAPI, "offsets not monotonic");
   }
   if (total && !data) return fail(REDGPU_EAPI, "null data buffer");
-  DeviceScope scope(dfa->device);
+  DeviceScope scope(dfa->im->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
 
   hipStream_t s = nullptr;
@@ -168,59 +190,50 @@ int collectDev(const redgpu_dfa *dfa, int listVerb, const uint8_t *data, const u
                uint64_t stride, uint64_t n, uint64_t cap, uint64_t *counts, int32_t *result,
                uint64_t *start, uint64_t *end, hipStream_t stream) {
   if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
-  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (dfa->im->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
   if (n == 0) return REDGPU_OK;
   if (!counts) return fail(REDGPU_EAPI, "null counts buffer");
   if (cap && !result) return fail(REDGPU_EAPI, "null result buffer");
   if (!data && (offsets || stride)) return fail(REDGPU_EAPI, "null data buffer");
-  DeviceScope scope(dfa->device);
+  DeviceScope scope(dfa->im->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   Batch b{data, offsets, stride, n, result, start, end};
   LaunchCfg cfg{dfa->numCUs, 0};
   hipError_t e = listVerb == kListCollect
-                     ? launchCollect(dfa->dev, b, cap, counts, cfg, stream)
-                     : launchMatchAll(dfa->dev, b, cap, counts, listVerb == kListMatchAllLeader,
+                     ? launchCollect(dfa->im->dev, b, cap, counts, cfg, stream)
+                     : launchMatchAll(dfa->im->dev, b, cap, counts, listVerb == kListMatchAllLeader,
                                       cfg, stream);
   tlsKernel = listVerb == kListCollect ? "k_collect" : "k_matchall";
   if (e != hipSuccess) return failHip(e, "kernel launch");
   return REDGPU_OK;
 }
 
-// (Re)uploads h->img to h->device; frees what was there before.  Caller holds the device scope.
-void freeDeviceImage(redgpu_dfa *h) {
-  if (h->dTable) (void)hipFree(h->dTable);
-  if (h->dResult) (void)hipFree(h->dResult);
-  if (h->dEquivLeader) (void)hipFree(h->dEquivLeader);
-  h->dTable = h->dResult = h->dEquivLeader = nullptr;
-}
-
-int uploadImage(redgpu_dfa *h) {
-  freeDeviceImage(h);
-  const DfaImage &img = h->img;
+// Uploads im->img to im->device.  Caller holds the device scope.
+int uploadImage(SharedImage *im) {
+  const DfaImage &img = im->img;
   uint8_t eqLead[512];
   std::memcpy(eqLead, img.equiv, 256);
   std::memcpy(eqLead + 256, img.leader, 256);
   const size_t tabBytes = (img.table.size() + 15) & ~size_t(15);
   hipError_t e;
-  auto bail = [&](hipError_t er, const char *what) { return failHip(er, what); };
-  if ((e = hipMalloc(&h->dTable, tabBytes + 16)) != hipSuccess) return bail(e, "hipMalloc table");
-  if ((e = hipMalloc(&h->dResult, img.nStates * sizeof(int32_t) + 16)) != hipSuccess)
-    return bail(e, "hipMalloc result");
-  if ((e = hipMalloc(&h->dEquivLeader, 512)) != hipSuccess) return bail(e, "hipMalloc equiv");
-  if ((e = hipMemset(h->dTable, 0, tabBytes + 16)) != hipSuccess) return bail(e, "hipMemset");
-  if ((e = hipMemcpy(h->dTable, img.table.data(), img.table.size(), hipMemcpyHostToDevice)) !=
+  if ((e = hipMalloc(&im->dTable, tabBytes + 16)) != hipSuccess) return failHip(e, "hipMalloc table");
+  if ((e = hipMalloc(&im->dResult, img.nStates * sizeof(int32_t) + 16)) != hipSuccess)
+    return failHip(e, "hipMalloc result");
+  if ((e = hipMalloc(&im->dEquivLeader, 512)) != hipSuccess) return failHip(e, "hipMalloc equiv");
+  if ((e = hipMemset(im->dTable, 0, tabBytes + 16)) != hipSuccess) return failHip(e, "hipMemset");
+  if ((e = hipMemcpy(im->dTable, img.table.data(), img.table.size(), hipMemcpyHostToDevice)) !=
       hipSuccess)
-    return bail(e, "upload table");
-  if ((e = hipMemcpy(h->dResult, img.result.data(), img.nStates * sizeof(int32_t),
+    return failHip(e, "upload table");
+  if ((e = hipMemcpy(im->dResult, img.result.data(), img.nStates * sizeof(int32_t),
                      hipMemcpyHostToDevice)) != hipSuccess)
-    return bail(e, "upload result");
-  if ((e = hipMemcpy(h->dEquivLeader, eqLead, 512, hipMemcpyHostToDevice)) != hipSuccess)
-    return bail(e, "upload equiv");
+    return failHip(e, "upload result");
+  if ((e = hipMemcpy(im->dEquivLeader, eqLead, 512, hipMemcpyHostToDevice)) != hipSuccess)
+    return failHip(e, "upload equiv");
 
-  DevDfa &d = h->dev;
-  d.table = static_cast<const uint8_t *>(h->dTable);
-  d.result = static_cast<const int32_t *>(h->dResult);
-  d.equivLeader = static_cast<const uint8_t *>(h->dEquivLeader);
+  DevDfa &d = im->dev;
+  d.table = static_cast<const uint8_t *>(im->dTable);
+  d.result = static_cast<const int32_t *>(im->dResult);
+  d.equivLeader = static_cast<const uint8_t *>(im->dEquivLeader);
   d.tableKind = img.tableKind;
   d.tableBytes = uint32_t(tabBytes);
   d.nStates = img.nStates;
@@ -238,6 +251,34 @@ int uploadImage(redgpu_dfa *h) {
   d.earlyDeath = img.earlyDeath ? 1 : 0;
   return REDGPU_OK;
 }
+
+// Loader cache (the reference's load path, lib/Serializer.cpp:257-267, hands
+// every caller its own Executable): a service that creates many handles from the same blob pays
+// for validation, repack and upload once per (blob, device, build options).  Entries are weak:
+// the image goes away with its last handle.
+struct CacheKey {
+  uint32_t checksum;
+  size_t len;
+  int device;
+  uint32_t buildFlags, ldsTableMax;
+  bool operator==(const CacheKey &o) const {
+    return checksum == o.checksum && len == o.len && device == o.device &&
+           buildFlags == o.buildFlags && ldsTableMax == o.ldsTableMax;
+  }
+};
+struct CacheKeyHash {
+  size_t operator()(const CacheKey &k) const {
+    uint64_t h = k.checksum;
+    h = h * 1099511628211ull ^ k.len;
+    h = h * 1099511628211ull ^ uint64_t(uint32_t(k.device));
+    h = h * 1099511628211ull ^ k.buildFlags;
+    h = h * 1099511628211ull ^ k.ldsTableMax;
+    return size_t(h);
+  }
+};
+std::mutex gCacheMutex;
+std::unordered_map<CacheKey, std::weak_ptr<SharedImage>, CacheKeyHash> gCache;
+constexpr uint32_t kBuildFlagMask = REDGPU_F_FORCE_GLOBAL | REDGPU_F_FORCE_HOT;
 
 } // namespace
 
@@ -262,58 +303,79 @@ int redgpu_dfa_create(const void *reda, size_t len, const redgpu_opts *opts, red
   redgpu_opts o{};
   o.device = REDGPU_DEVICE_CURRENT;
   if (opts) o = *opts;
+  if (!reda || len == 0) return fail(REDGPU_EAPI, "serialized dfa is empty");
+  if (const char *m = checkHeader(reda, len)) return fail(REDGPU_EAPI, m);
+
+  int dev = o.device;
+  int numCUs = 0;
+  if (dev != REDGPU_DEVICE_NONE) {
+    if (dev == REDGPU_DEVICE_CURRENT) {
+      hipError_t e = hipGetDevice(&dev);
+      if (e != hipSuccess) return failHip(e, "hipGetDevice");
+    }
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return failHip(e, "hipGetDeviceProperties");
+    numCUs = prop.multiProcessorCount;
+  }
 
   redgpu_dfa *h = new (std::nothrow) redgpu_dfa();
   if (!h) return fail(REDGPU_ELIMIT, "out of host memory");
+  h->flags = o.flags;
+  h->ldsTableMax = o.lds_table_max;
+  h->numCUs = numCUs;
+
+  // the header is valid, so the checksum is the FNV-1a-32 of the payload: the cache key
+  const CacheKey key{calcChecksum(reda, len), len, dev, o.flags & kBuildFlagMask, o.lds_table_max};
+  {
+    std::lock_guard<std::mutex> lock(gCacheMutex);
+    auto it = gCache.find(key);
+    if (it != gCache.end()) {
+      if (std::shared_ptr<SharedImage> hit = it->second.lock()) {
+        if (hit->blob.size() == len && std::memcmp(hit->blob.data(), reda, len) == 0) {
+          h->im = std::move(hit);
+          *out = h;
+          return REDGPU_OK;
+        }
+      } else {
+        gCache.erase(it);
+      }
+    }
+  }
+
+  auto im = std::make_shared<SharedImage>();
   int code = REDGPU_OK;
   std::string err = buildImage(reda, len, o.lds_table_max, (o.flags & REDGPU_F_FORCE_GLOBAL) != 0,
-                               h->img, code, (o.flags & REDGPU_F_FORCE_HOT) != 0);
+                               im->img, code, (o.flags & REDGPU_F_FORCE_HOT) != 0);
   if (!err.empty()) {
     delete h;
     return fail(code, err);
   }
-  h->blob.assign(static_cast<const uint8_t *>(reda), static_cast<const uint8_t *>(reda) + len);
-  h->flags = o.flags;
-  h->ldsTableMax = o.lds_table_max;
-  if (o.device == REDGPU_DEVICE_NONE) {
-    h->device = REDGPU_DEVICE_NONE;
-    *out = h;
-    return REDGPU_OK;
+  im->blob.assign(static_cast<const uint8_t *>(reda), static_cast<const uint8_t *>(reda) + len);
+  im->buildFlags = key.buildFlags;
+  im->ldsTableMax = o.lds_table_max;
+  im->device = dev;
+  if (dev != REDGPU_DEVICE_NONE) {
+    DeviceScope scope(dev);
+    if (scope.err != hipSuccess) { delete h; return failHip(scope.err, "hipSetDevice"); }
+    if (int rc = uploadImage(im.get())) { delete h; return rc; }
   }
-
-  int dev = o.device;
-  if (dev == REDGPU_DEVICE_CURRENT) {
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) { delete h; return failHip(e, "hipGetDevice"); }
-  }
-  DeviceScope scope(dev);
-  if (scope.err != hipSuccess) { delete h; return failHip(scope.err, "hipSetDevice"); }
-  hipDeviceProp_t prop;
-  hipError_t e = hipGetDeviceProperties(&prop, dev);
-  if (e != hipSuccess) { delete h; return failHip(e, "hipGetDeviceProperties"); }
-  h->device = dev;
-  h->numCUs = prop.multiProcessorCount;
-
-  if (int rc = uploadImage(h)) {
-    redgpu_dfa_destroy(h);
-    return rc;
+  h->im = im;
+  {
+    std::lock_guard<std::mutex> lock(gCacheMutex);
+    gCache[key] = im;
   }
   *out = h;
   return REDGPU_OK;
 }
 
 void redgpu_dfa_destroy(redgpu_dfa *h) {
-  if (!h) return;
-  if (h->device >= 0) {
-    DeviceScope scope(h->device);
-    freeDeviceImage(h);
-  }
-  delete h;
+  delete h;  // the shared image goes with its last handle (~SharedImage frees the device side)
 }
 
 int redgpu_dfa_info(const redgpu_dfa *h, redgpu_info *out) {
   if (!h || !out) return fail(REDGPU_EAPI, "null argument");
-  const DfaImage &img = h->img;
+  const DfaImage &img = h->im->img;
   out->format = img.format;
   out->n_classes = img.nClasses;
   out->leader_len = img.leaderLen;
@@ -324,7 +386,7 @@ int redgpu_dfa_info(const redgpu_dfa *h, redgpu_info *out) {
   out->table_kind = img.tableKind;
   out->table_bytes = img.table.size();
   out->max_result = img.maxResult;
-  out->device = h->device;
+  out->device = h->im->device;
   out->checksum = img.checksum;
   out->fast_path = (img.tableKind == REDGPU_TAB_LDS_FUSED_U8 && img.deadAbsorbing &&
                     !(h->flags & REDGPU_F_FORCE_GENERIC)) ? 1 : 0;
@@ -332,13 +394,14 @@ int redgpu_dfa_info(const redgpu_dfa *h, redgpu_info *out) {
   out->hot_lo = img.hotLo;
   out->hot_coverage_ppm = img.hotCoveragePpm;
   out->early_death = img.earlyDeath ? 1 : 0;
+  out->image_refs = uint32_t(h->im.use_count());
   return REDGPU_OK;
 }
 
 int redgpu_dfa_serialized(const redgpu_dfa *h, const void **reda, size_t *len) {
   if (!h || !reda || !len) return fail(REDGPU_EAPI, "null argument");
-  *reda = h->blob.data();
-  *len = h->blob.size();
+  *reda = h->im->blob.data();
+  *len = h->im->blob.size();
   return REDGPU_OK;
 }
 
@@ -409,12 +472,12 @@ static int listHost(const redgpu_dfa *dfa, int listVerb, const uint8_t *data,
                     const uint64_t *offsets, uint64_t stride, uint64_t n, uint64_t cap,
                     uint64_t *counts, int32_t *result, uint64_t *start, uint64_t *end) {
   if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
-  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (dfa->im->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
   if (n == 0) return REDGPU_OK;
   if (!counts) return fail(REDGPU_EAPI, "null counts buffer");
   const uint64_t total = offsets ? offsets[n] : stride * n;
   if (total && !data) return fail(REDGPU_EAPI, "null data buffer");
-  DeviceScope scope(dfa->device);
+  DeviceScope scope(dfa->im->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   uint8_t *dData = nullptr;
   uint64_t *dOff = nullptr, *dCnt = nullptr, *dStart = nullptr, *dEnd = nullptr;
@@ -460,7 +523,7 @@ int redgpu_replace_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, co
                              uint64_t *counts, uint64_t *out_offsets, uint8_t *out,
                              uint64_t out_cap, void *stream) {
   if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
-  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (dfa->im->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
   if (int rc = checkStyle(style)) return rc;
   if (n == 0) return REDGPU_OK;
   if (!counts || !out_offsets) return fail(REDGPU_EAPI, "null output buffer");
@@ -468,11 +531,11 @@ int redgpu_replace_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, co
   if (repl_len && !repl) return fail(REDGPU_EAPI, "null replacement");
   if (offsets && stride > 16) return fail(REDGPU_EAPI, "with offsets, stride is the number of "
                                                        "trailing bytes to drop per line (0..16)");
-  DeviceScope scope(dfa->device);
+  DeviceScope scope(dfa->im->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   Batch b{data, offsets, stride, n, nullptr, nullptr, nullptr};
   LaunchCfg cfg{dfa->numCUs, 0};
-  hipError_t e = launchReplace(dfa->dev, b, style, do_leader ? 1 : 0, repl, repl_len, max_count,
+  hipError_t e = launchReplace(dfa->im->dev, b, style, do_leader ? 1 : 0, repl, repl_len, max_count,
                                counts, out_offsets, out, out_cap, cfg,
                                static_cast<hipStream_t>(stream));
   tlsKernel = "k_replace";
@@ -485,7 +548,7 @@ int redgpu_replace_batch(const redgpu_dfa *dfa, int style, int do_leader, const 
                          uint64_t repl_len, uint64_t max_count, uint64_t *counts,
                          uint64_t *out_offsets, uint8_t *out, uint64_t out_cap) {
   if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
-  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (dfa->im->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
   if (int rc = checkStyle(style)) return rc;
   if (n == 0) return REDGPU_OK;
   if (!counts || !out_offsets) return fail(REDGPU_EAPI, "null output buffer");
@@ -496,7 +559,7 @@ int redgpu_replace_batch(const redgpu_dfa *dfa, int style, int do_leader, const 
   }
   if (total && !data) return fail(REDGPU_EAPI, "null data buffer");
   if (repl_len && !repl) return fail(REDGPU_EAPI, "null replacement");
-  DeviceScope scope(dfa->device);
+  DeviceScope scope(dfa->im->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   uint8_t *dData = nullptr, *dRepl = nullptr, *dOut = nullptr;
   uint64_t *dOff = nullptr, *dCnt = nullptr, *dOutOff = nullptr;
@@ -546,11 +609,11 @@ int redgpu_replace_batch(const redgpu_dfa *dfa, int style, int do_leader, const 
 int redgpu_split_lines_dev(const redgpu_dfa *dfa, const uint8_t *data, uint64_t len, uint8_t delim,
                            uint64_t *offsets, uint64_t cap, uint64_t *n_lines, void *stream) {
   if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
-  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (dfa->im->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
   if (!offsets || !n_lines) return fail(REDGPU_EAPI, "null output buffer");
   if (len && !data) return fail(REDGPU_EAPI, "null data buffer");
   if (splitChunks(len) >= (1ull << 31)) return fail(REDGPU_ELIMIT, "buffer too large");
-  DeviceScope scope(dfa->device);
+  DeviceScope scope(dfa->im->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const uint64_t nChunks = splitChunks(len);
@@ -571,10 +634,10 @@ int redgpu_split_lines_dev(const redgpu_dfa *dfa, const uint8_t *data, uint64_t 
 int redgpu_split_lines(const redgpu_dfa *dfa, const uint8_t *data, uint64_t len, uint8_t delim,
                        uint64_t *offsets, uint64_t cap, uint64_t *n_lines) {
   if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
-  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (dfa->im->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
   if (!offsets || !n_lines) return fail(REDGPU_EAPI, "null output buffer");
   if (len && !data) return fail(REDGPU_EAPI, "null data buffer");
-  DeviceScope scope(dfa->device);
+  DeviceScope scope(dfa->im->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   uint8_t *dData = nullptr;
   uint64_t *dOff = nullptr, *dN = nullptr;
@@ -606,10 +669,10 @@ int redgpu_split_lines(const redgpu_dfa *dfa, const uint8_t *data, uint64_t len,
 int redgpu_diag_read_dev(const redgpu_dfa *dfa, const void *data, uint64_t bytes, uint32_t *sink,
                          void *stream) {
   if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
-  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (dfa->im->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
   if (!data || !sink) return fail(REDGPU_EAPI, "null buffer");
   if (reinterpret_cast<uintptr_t>(data) % 16) return fail(REDGPU_EAPI, "buffer not 16-byte aligned");
-  DeviceScope scope(dfa->device);
+  DeviceScope scope(dfa->im->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   hipError_t e = launchDiagRead(data, bytes, sink, dfa->numCUs, static_cast<hipStream_t>(stream));
   tlsKernel = "k_diag_read";
@@ -620,17 +683,17 @@ int redgpu_diag_read_dev(const redgpu_dfa *dfa, const void *data, uint64_t bytes
 int redgpu_dfa_tune_dev(redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,
                         uint64_t stride, uint64_t n, void *stream) {
   if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
-  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (dfa->im->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
   if (n == 0) return REDGPU_OK;
   if (!data && (offsets || stride)) return fail(REDGPU_EAPI, "null data buffer");
-  DeviceScope scope(dfa->device);
+  DeviceScope scope(dfa->im->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   // a table that is in LDS whole has nothing to re-rank
-  if (dfa->img.tableKind == REDGPU_TAB_LDS_FUSED_U8 || dfa->img.tableKind == REDGPU_TAB_LDS_FUSED_U16 ||
-      dfa->img.tableKind == REDGPU_TAB_LDS_CLASS_U16)
+  if (dfa->im->img.tableKind == REDGPU_TAB_LDS_FUSED_U8 || dfa->im->img.tableKind == REDGPU_TAB_LDS_FUSED_U16 ||
+      dfa->im->img.tableKind == REDGPU_TAB_LDS_CLASS_U16)
     return REDGPU_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const uint32_t nStates = dfa->img.nStates;
+  const uint32_t nStates = dfa->im->img.nStates;
   uint32_t *dHist = nullptr;
   HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dHist), size_t(nStates) * 4), "hipMalloc histogram");
   auto done = [&](int rc) { (void)hipFree(dHist); return rc; };
@@ -638,7 +701,7 @@ int redgpu_dfa_tune_dev(redgpu_dfa *dfa, const uint8_t *data, const uint64_t *of
   if (e != hipSuccess) return done(failHip(e, "hipMemsetAsync"));
   Batch b{data, offsets, stride, n, nullptr, nullptr, nullptr};
   LaunchCfg cfg{dfa->numCUs, 0};
-  e = launchVisits(dfa->dev, b, dHist, cfg, s);
+  e = launchVisits(dfa->im->dev, b, dHist, cfg, s);
   tlsKernel = "k_visits";
   if (e != hipSuccess) return done(failHip(e, "kernel launch"));
   std::vector<uint32_t> hist(nStates);
@@ -649,25 +712,33 @@ int redgpu_dfa_tune_dev(redgpu_dfa *dfa, const uint8_t *data, const uint64_t *of
   dHist = nullptr;
 
   // device index -> blob state id, then the same builder with the observed visits
-  std::vector<double> measured(dfa->img.statesTotal, 0.0);
-  for (uint32_t i = 0; i < nStates; ++i) measured[dfa->img.rawOf[i]] = double(hist[i]);
+  std::vector<double> measured(dfa->im->img.statesTotal, 0.0);
+  for (uint32_t i = 0; i < nStates; ++i) measured[dfa->im->img.rawOf[i]] = double(hist[i]);
   DfaImage img;
   int code = REDGPU_OK;
-  std::string err = buildImage(dfa->blob.data(), dfa->blob.size(), dfa->ldsTableMax,
+  std::string err = buildImage(dfa->im->blob.data(), dfa->im->blob.size(), dfa->ldsTableMax,
                                (dfa->flags & REDGPU_F_FORCE_GLOBAL) != 0, img, code,
                                (dfa->flags & REDGPU_F_FORCE_HOT) != 0, &measured);
   if (!err.empty()) return fail(code, err);
   // all work queued on the device so far may still read the old tables
   e = hipDeviceSynchronize();
   if (e != hipSuccess) return failHip(e, "hipDeviceSynchronize");
-  dfa->img = std::move(img);
-  return uploadImage(dfa);
+  // copy on tune: other handles that share the image keep the one they were created with
+  auto im = std::make_shared<SharedImage>();
+  im->blob = dfa->im->blob;
+  im->img = std::move(img);
+  im->device = dfa->im->device;
+  im->buildFlags = dfa->im->buildFlags;
+  im->ldsTableMax = dfa->im->ldsTableMax;
+  if (int rc = uploadImage(im.get())) return rc;
+  dfa->im = std::move(im);
+  return REDGPU_OK;
 }
 
 int redgpu_dfa_tune(redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets, uint64_t stride,
                     uint64_t n) {
   if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
-  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (dfa->im->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
   if (n == 0) return REDGPU_OK;
   const uint64_t total = offsets ? offsets[n] : stride * n;
   if (offsets) {
@@ -675,7 +746,7 @@ int redgpu_dfa_tune(redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offset
       if (offsets[i] > offsets[i + 1]) return fail(REDGPU_EAPI, "offsets not monotonic");
   }
   if (total && !data) return fail(REDGPU_EAPI, "null data buffer");
-  DeviceScope scope(dfa->device);
+  DeviceScope scope(dfa->im->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   uint8_t *dData = nullptr;
   uint64_t *dOff = nullptr;
@@ -705,17 +776,17 @@ int redgpu_advance_batch_dev(const redgpu_dfa *dfa, const uint8_t *data, const u
                              uint64_t stride, uint64_t n, uint32_t *state, int32_t *result,
                              void *stream) {
   if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
-  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (dfa->im->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
   if (n == 0) return REDGPU_OK;
   if (!state) return fail(REDGPU_EAPI, "null state buffer");
   if (!result) return fail(REDGPU_EAPI, "null result buffer");
   if (!data && (offsets || stride)) return fail(REDGPU_EAPI, "null data buffer");
-  DeviceScope scope(dfa->device);
+  DeviceScope scope(dfa->im->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   Batch b{data, offsets, stride, n, result, nullptr, nullptr};
   LaunchCfg cfg{dfa->numCUs, (dfa->flags & REDGPU_F_FORCE_GENERIC) ? 1 : 0};
   const char *name = "";
-  hipError_t e = launchAdvance(dfa->dev, b, state, cfg, static_cast<hipStream_t>(stream), &name);
+  hipError_t e = launchAdvance(dfa->im->dev, b, state, cfg, static_cast<hipStream_t>(stream), &name);
   tlsKernel = name;
   if (e != hipSuccess) return failHip(e, "kernel launch");
   return REDGPU_OK;
@@ -724,7 +795,7 @@ int redgpu_advance_batch_dev(const redgpu_dfa *dfa, const uint8_t *data, const u
 int redgpu_advance_batch(const redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,
                          uint64_t stride, uint64_t n, uint32_t *state, int32_t *result) {
   if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
-  if (dfa->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (dfa->im->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
   if (n == 0) return REDGPU_OK;
   if (!state) return fail(REDGPU_EAPI, "null state buffer");
   if (!result) return fail(REDGPU_EAPI, "null result buffer");
@@ -734,7 +805,7 @@ int redgpu_advance_batch(const redgpu_dfa *dfa, const uint8_t *data, const uint6
       if (offsets[i] > offsets[i + 1]) return fail(REDGPU_EAPI, "offsets not monotonic");
   }
   if (total && !data) return fail(REDGPU_EAPI, "null data buffer");
-  DeviceScope scope(dfa->device);
+  DeviceScope scope(dfa->im->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   uint8_t *dData = nullptr;
   uint64_t *dOff = nullptr;

@@ -126,3 +126,26 @@ def test_all_golden_blobs_repack():
         assert exe.info["states_used"] >= 1
         n += 1
     assert n == 566
+
+
+def test_loader_cache_shares_images():
+    """Same blob + device + build options -> one image (redgpu_info.image_refs); different
+    options or different bytes -> their own; the image goes with its last handle."""
+    blob = load_dfa("uri")
+    a = one_amd.Executable(blob, device="none")
+    assert a.info["image_refs"] == 1
+    b = one_amd.Executable(bytearray(blob), device="none")
+    assert a.info["image_refs"] == 2 and b.info["image_refs"] == 2
+    c = one_amd.Executable(blob, device="none", force_global=True)      # other build options
+    d = one_amd.Executable(blob, device="none", force_generic=True)     # handle-level flag only
+    assert c.info["image_refs"] == 1 and c.info["table_kind"] == 4
+    assert d.info["image_refs"] == 3 and a.info["table_kind"] == 1
+    e = one_amd.Executable(load_dfa("err"), device="none")
+    assert e.info["image_refs"] == 1
+    b.close()
+    d.close()
+    assert a.info["image_refs"] == 1
+    assert a.serialized() == blob
+    a.close()
+    f = one_amd.Executable(blob, device="none")                          # rebuilt from scratch
+    assert f.info["image_refs"] == 1 and f.serialized() == blob

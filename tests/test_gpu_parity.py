@@ -436,6 +436,27 @@ def test_replace_on_gpu():
     assert counts.tolist() == [1, 1, 0, 1] and out.tobytes() == b"aNbN cN"
 
 
+def test_loader_cache_on_device_and_tune_detaches():
+    """Two handles from one blob share the device image; tuning one gives it a private image and
+    leaves the other's results and state tokens untouched."""
+    blob = load_dfa("uri_v6")
+    a, b = one_amd.Executable(blob), one_amd.Executable(blob)
+    assert a.info["image_refs"] == 2
+    n, L = 2048, 256
+    text = W.fixed_lines(n, L, 41, alphabet=True, plant=W.URI_PLANT, plant_every=2, plant_at=30)
+    exp = O.CpuOracle(blob).batch("match", 4, 0, text, stride=L, n=n, threads=4)
+    state = np.full(n, one_amd.STATE_INITIAL, dtype=np.uint32)
+    one_amd.advance_batch(b, text[:n * L // 2], state[:n // 2].copy(), stride=L, n=n // 2)
+    a.tune(text, stride=L, n=n)
+    assert a.info["image_refs"] == 1 and b.info["image_refs"] == 1
+    for exe in (a, b):
+        got = one_amd.match_batch(exe, text, 4, 0, stride=L, n=n)
+        for g, e in zip(got, exp):
+            assert np.array_equal(g, e)
+    c = one_amd.Executable(blob)          # the cache still holds b's (untuned) image
+    assert b.info["image_refs"] == 2 and c.info["hot_lo"] == b.info["hot_lo"]
+
+
 def test_edge_cases():
     exe = one_amd.Executable(load_dfa("err"))
     cpu = O.CpuOracle(load_dfa("err"))

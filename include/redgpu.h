@@ -63,6 +63,8 @@ typedef struct redgpu_opts {
 #define REDGPU_F_FORCE_GLOBAL  2u /* keep the transition table in HBM/L2 even if it fits LDS */
 #define REDGPU_F_NO_BUCKETING  8u /* ragged fast path: walk lines in input order instead of
                                      bucketing them by length first (tests, tuning) */
+#define REDGPU_F_FORCE_STREAM 16u /* whole-line streaming kernels even for a DFA flagged
+                                     early_death (tests, tuning) */
 #define REDGPU_F_FORCE_HOT     4u /* a table too big for LDS always gets hot rows in LDS, even
                                      when the visit model finds no locality (tests, tuning) */
 

@@ -11,7 +11,7 @@ HEADER = os.path.join(os.path.dirname(HERE), "include", "redgpu.h")
 
 OK, EAPI, EEXEC, ELIMIT, EHIP = 0, -1, -2, -3, -5
 DEVICE_CURRENT, DEVICE_NONE = -1, -2
-F_FORCE_GENERIC, F_FORCE_GLOBAL, F_FORCE_HOT, F_NO_BUCKETING = 1, 2, 4, 8
+F_FORCE_GENERIC, F_FORCE_GLOBAL, F_FORCE_HOT, F_NO_BUCKETING, F_FORCE_STREAM = 1, 2, 4, 8, 16
 
 
 class Opts(C.Structure):

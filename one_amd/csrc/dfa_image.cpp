@@ -187,8 +187,11 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
   // (power iteration over the class table, class weights = bytes per class); ties - states the
   // model never reaches, e.g. deep inside a signature - go by breadth-first distance from
   // the initial state.  Pure dead ends are never looked up (the walk stops there).
+  // The model is also what flags "early death" for every placement (it is skipped for tables so
+  // large that the iteration itself would take long).
   std::vector<uint8_t> isHot(stateCnt, 0);
-  if (img.tableKind == REDGPU_TAB_HOT_ROWS) {
+  const bool wantHot = img.tableKind == REDGPU_TAB_HOT_ROWS;
+  if (wantHot || uint64_t(reach.size()) * nCls <= (8ull << 20)) {
     std::vector<double> w(nCls, 0.0);
     for (uint32_t b = 0; b < 256; ++b) {
       double wb = 0.5 / 256.0;
@@ -223,6 +226,7 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
         for (uint32_t s : reach)
           visits[s] = (*measured)[s] / msum + 1e-9 * (vsum > 0.0 ? visits[s] / vsum : 0.0);
     }
+    if (wantHot) {
     std::vector<uint32_t> cand;
     double total = 0.0;
     for (uint32_t s : reach)
@@ -254,6 +258,7 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
       img.nHot = rows;
       img.hotCoveragePpm = uint32_t(coverage(rows) * 1e6);
     }
+    }  // wantHot
   }
 
   // order: pure dead ends | non-accepting | accepting (stable in blob order); with hot rows

@@ -49,6 +49,7 @@ struct LaunchCfg {
   int numCUs;
   int forceGeneric;
   int noBucketing = 0;  // k_ragged: keep lines in input order (REDGPU_F_NO_BUCKETING)
+  int forceStream = 0;  // whole-line kernels even for early-death DFAs (REDGPU_F_FORCE_STREAM)
 };
 
 // Launches the kernel for (verb, style, doLeader) on `stream`; returns hipSuccess or the

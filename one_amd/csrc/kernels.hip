@@ -1204,7 +1204,7 @@ hipError_t launchFixedS(int style, const DevDfa &d, const Batch &b, uint32_t sta
 // REDGPU_TAB_HOT_ROWS DFAs whose hot set the streaming kernel can index with one byte
 static bool hotStreamEligible(const DevDfa &d) {
   return d.tableKind == REDGPU_TAB_HOT_ROWS && d.nHot > 0 && d.hot8Off != 0 &&
-         d.deadAbsorbing && !d.earlyDeath;
+         d.deadAbsorbing;
 }
 
 bool fastPathEligible(const DevDfa &d) {
@@ -1380,10 +1380,15 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
     return hipSuccess;
   }
   const bool lead = doLeader && d.leaderLen > 0;
+  // DFAs the visit model sees dying within 16 bytes (anchored patterns on arbitrary text) stay
+  // with k_generic: the whole-line kernels below read and walk every byte, k_generic stops
+  // where the reference's loop stops - measured on ERR 1.3x (64-byte lines) to 38x (4 KiB
+  // lines) faster (scripts/bench_anchored.py).
+  const bool dying = d.earlyDeath && !cfg.forceStream;
   // Fixed-stride hot path: check / match, whole 16-byte multiples, 16-byte aligned base.
   // check<.., true> consumes the leader and starts in the post-leader state at byte
   // leaderLen (Matcher.h:370-375); match only peeks it (Matcher.h:424-435).
-  const bool fixedOk = !cfg.forceGeneric && fastPathEligible(d) && !b.offsets &&
+  const bool fixedOk = !cfg.forceGeneric && !dying && fastPathEligible(d) && !b.offsets &&
                        (verb == kCheck || verb == kMatch) && b.stride >= 16 &&
                        b.stride % 16 == 0 && b.stride < (1ull << 31) &&
                        (reinterpret_cast<uintptr_t>(b.data) % 16) == 0 &&
@@ -1412,7 +1417,7 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
   }
   // The same streaming walk for DFAs too big for LDS: hot rows as a one-byte-indexed table,
   // cold excursions re-walked per 64-byte half-block (k_stream.h, HOT).
-  const bool hotStreamOk = !cfg.forceGeneric && hotStreamEligible(d) && !b.offsets &&
+  const bool hotStreamOk = !cfg.forceGeneric && !dying && hotStreamEligible(d) && !b.offsets &&
                            (verb == kCheck || verb == kMatch) &&
                            (style == kStyLast || style == kStyFull) && b.stride >= 64 &&
                            b.stride % 64 == 0 && b.stride < (1ull << 31) &&
@@ -1461,7 +1466,7 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
   // Ragged lines, fused-u8 table, styles Last / Full of check / match, no leader to honour:
   // k_ragged walks every line; blocks that would reach past the end of the buffer come from a
   // padded copy of its last bytes.
-  const bool raggedOk = !cfg.forceGeneric && fastPathEligible(d) && b.offsets &&
+  const bool raggedOk = !cfg.forceGeneric && !dying && fastPathEligible(d) && b.offsets &&
                         (verb == kCheck || verb == kMatch) &&
                         (style == kStyLast || style == kStyFull) && !lead &&
                         d.tableBytes <= kStreamTabBytes && d.nStates <= 256;

@@ -113,7 +113,8 @@ int runDev(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint8
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   Batch b{data, offsets, stride, n, result, start, end};
   LaunchCfg cfg{dfa->numCUs, (dfa->flags & REDGPU_F_FORCE_GENERIC) ? 1 : 0,
-                (dfa->flags & REDGPU_F_NO_BUCKETING) ? 1 : 0};
+                (dfa->flags & REDGPU_F_NO_BUCKETING) ? 1 : 0,
+                (dfa->flags & REDGPU_F_FORCE_STREAM) ? 1 : 0};
   const char *name = "";
   hipError_t e = launchBatch(dfa->im->dev, b, verb, style, doLeader ? 1 : 0, cfg, stream, &name);
   tlsKernel = name;
@@ -389,7 +390,8 @@ int redgpu_dfa_info(const redgpu_dfa *h, redgpu_info *out) {
   out->device = h->im->device;
   out->checksum = img.checksum;
   out->fast_path = (img.tableKind == REDGPU_TAB_LDS_FUSED_U8 && img.deadAbsorbing &&
-                    !(h->flags & REDGPU_F_FORCE_GENERIC)) ? 1 : 0;
+                    !(h->flags & REDGPU_F_FORCE_GENERIC) &&
+                    (!img.earlyDeath || (h->flags & REDGPU_F_FORCE_STREAM))) ? 1 : 0;
   out->n_hot = img.nHot;
   out->hot_lo = img.hotLo;
   out->hot_coverage_ppm = img.hotCoveragePpm;
@@ -652,14 +654,23 @@ int redgpu_split_lines(const redgpu_dfa *dfa, const uint8_t *data, uint64_t len,
     if (e_ != hipSuccess) { rc = failHip(e_, what); cleanup(); return rc; }   \
   } while (0)
   SP_TRY(hipMalloc(reinterpret_cast<void **>(&dData), len + 16), "hipMalloc data");
-  SP_TRY(hipMalloc(reinterpret_cast<void **>(&dOff), (cap + 1) * 8), "hipMalloc offsets");
   SP_TRY(hipMalloc(reinterpret_cast<void **>(&dN), 8), "hipMalloc count");
   if (len) SP_TRY(hipMemcpy(dData, data, len, hipMemcpyHostToDevice), "copy data");
-  rc = redgpu_split_lines_dev(dfa, dData, len, delim, dOff, cap, dN, nullptr);
+  // count first (room for no line at all), then size the device offsets to what will be kept
+  SP_TRY(hipMalloc(reinterpret_cast<void **>(&dOff), 8), "hipMalloc offsets");
+  rc = redgpu_split_lines_dev(dfa, dData, len, delim, dOff, 0, dN, nullptr);
   if (rc != REDGPU_OK) { cleanup(); return rc; }
   SP_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
   SP_TRY(hipMemcpy(n_lines, dN, 8, hipMemcpyDeviceToHost), "copy count");
   const uint64_t got = *n_lines < cap ? *n_lines : cap;
+  if (got) {
+    (void)hipFree(dOff);
+    dOff = nullptr;
+    SP_TRY(hipMalloc(reinterpret_cast<void **>(&dOff), (got + 1) * 8), "hipMalloc offsets");
+    rc = redgpu_split_lines_dev(dfa, dData, len, delim, dOff, got, dN, nullptr);
+    if (rc != REDGPU_OK) { cleanup(); return rc; }
+    SP_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  }
   SP_TRY(hipMemcpy(offsets, dOff, (got + 1) * 8, hipMemcpyDeviceToHost), "copy offsets");
 #undef SP_TRY
   cleanup();

@@ -77,6 +77,7 @@ class Executable:
 
     def __init__(self, serialized: bytes, device=None, *, force_generic=False,
                  force_global=False, force_hot=False, no_bucketing=False,
+                 force_stream=False,
                  lds_table_max=0):
         if serialized is None or len(serialized) == 0:
             raise RedExceptApi("serialized dfa string_view is empty")  # Executable.cpp:66
@@ -87,7 +88,8 @@ class Executable:
         o.flags = (_lib.F_FORCE_GENERIC if force_generic else 0) | \
                   (_lib.F_FORCE_GLOBAL if force_global else 0) | \
                   (_lib.F_FORCE_HOT if force_hot else 0) | \
-                  (_lib.F_NO_BUCKETING if no_bucketing else 0)
+                  (_lib.F_NO_BUCKETING if no_bucketing else 0) | \
+                  (_lib.F_FORCE_STREAM if force_stream else 0)
         self._h = C.c_void_p()
         blob = bytes(serialized)
         _check(_lib.lib().redgpu_dfa_create(blob, len(blob), C.byref(o), C.byref(self._h)))
@@ -418,12 +420,15 @@ def split_lines(exe, data, delim=b"\n", cap=None):
                                         torch.cuda.current_stream(data.device).cuda_stream))
         return offs, cnt
     a = _host_u8(data)
-    if cap is None:
-        cap = int(a.size)  # no more lines than bytes
-    offs = np.zeros(cap + 1, dtype=np.uint64)
     cnt = C.c_uint64(0)
-    _check(l.redgpu_split_lines(exe._h, a.ctypes.data if a.size else None, a.size, d,
-                                offs.ctypes.data, cap, C.byref(cnt)))
+    dp = a.ctypes.data if a.size else None
+    if cap is None:
+        # size the result exactly: a first call that keeps no line only counts
+        one = np.zeros(1, dtype=np.uint64)
+        _check(l.redgpu_split_lines(exe._h, dp, a.size, d, one.ctypes.data, 0, C.byref(cnt)))
+        cap = int(cnt.value)
+    offs = np.zeros(cap + 1, dtype=np.uint64)
+    _check(l.redgpu_split_lines(exe._h, dp, a.size, d, offs.ctypes.data, cap, C.byref(cnt)))
     return offs[: min(cnt.value, cap) + 1], int(cnt.value)
 
 

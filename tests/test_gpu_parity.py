@@ -108,9 +108,17 @@ def test_fixed_stride_hot_path_vs_oracle(name, stride, n):
     """The specialised fixed-stride kernels (k_fixed) against the oracle, all styles, check and
     match, with and without the leader, ragged tile counts."""
     blob = load_dfa(name)
-    exe = one_amd.Executable(blob)
+    # the anchored DFAs (err, num3) are flagged early_death and would take the early-exit generic
+    # kernel by default: force the whole-line kernels so their dead-end handling is what is tested
+    exe = one_amd.Executable(blob, force_stream=True)
     cpu = O.CpuOracle(blob)
     data = _fixed_inputs(name, n, stride, seed=stride + n)
+    if one_amd.Executable(blob).info["early_death"]:
+        dflt = one_amd.Executable(blob)
+        r, s, e = one_amd.match_batch(dflt, data, 4, 0, stride=stride, n=n)
+        assert one_amd.last_kernel() == "k_generic" and not dflt.info["fast_path"]
+        er, es, ee = cpu.batch("match", 4, 0, data, stride=stride, n=n, threads=4)
+        assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee)
     for si in range(1, 6):
         for lead in (0, 1):
             er, es, ee = cpu.batch("match", si, lead, data, stride=stride, n=n, threads=4)

@@ -162,6 +162,52 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
     return (hd & resultMask) ? 2 : 1;
   };
 
+  // start bytes (see dfa_image.h)
+  {
+    auto pack = [&](auto pred, uint32_t &word, uint32_t &count) {
+      uint32_t n = 0, w = 0;
+      for (uint32_t b = 0; b < 256; ++b)
+        if (pred(b)) {
+          if (n < 4) w |= b << (8 * n);
+          ++n;
+        }
+      // unused slots repeat the first member, so a 4-way test needs no count
+      for (uint32_t k = n; k < 4 && n > 0; ++k) w |= (w & 0xffu) << (8 * k);
+      word = w;
+      count = n <= 4 ? n : 0xffu;
+    };
+    if (leaderLen > 0)
+      pack([&](uint32_t b) { return h[kOffEquivMap + b] == h[kHeaderBytes]; }, img.startLeadWord,
+           img.startLeadCount);
+    pack([&](uint32_t b) {
+      uint32_t t = 0;
+      targetOf(rawInit, h[kOffEquivMap + b], t);
+      return klass(t) != 0;
+    }, img.startFreeWord, img.startFreeCount);
+    if (leaderLen > 1)
+      pack([&](uint32_t b) { return h[kOffEquivMap + b] == h[kHeaderBytes + 1]; },
+           img.start2LeadWord, img.start2LeadCount);
+    // second step without the leader: only meaningful when no first step accepts
+    std::vector<uint32_t> firsts;  // non-dead targets of the initial state
+    bool firstAccepts = false;
+    for (uint32_t c = 0; c < nCls; ++c) {
+      uint32_t t = 0;
+      targetOf(rawInit, c, t);
+      if (klass(t) == 0) continue;
+      if (klass(t) == 2) firstAccepts = true;
+      firsts.push_back(t);
+    }
+    if (!firstAccepts)
+      pack([&](uint32_t b) {
+        for (uint32_t f1 : firsts) {
+          uint32_t t = 0;
+          targetOf(f1, h[kOffEquivMap + b], t);
+          if (klass(t) != 0) return true;
+        }
+        return false;
+      }, img.start2FreeWord, img.start2FreeCount);
+  }
+
   // table placement (decided before the renumbering: the hot-row kind orders states its own way)
   if (ldsTableMax == 0)
     ldsTableMax = 144u * 1024u;

@@ -39,6 +39,18 @@ struct DfaImage {
   uint32_t firstAccept = 0;
   int32_t  maxResult = 0;
   bool     deadAbsorbing = true;  // every pure dead end self-loops on every class
+  // "Start bytes" for scan / search: the only input bytes at which an attempt can survive its
+  // first step - with the leader, the bytes of the leader's first class; without, the bytes
+  // whose transition out of the initial state is not a pure dead end.  Up to 4 are listed
+  // (packed, one per byte of the word) so that the kernels can test a whole input word at once;
+  // count 0xff = more than 4 (no word filter).
+  uint32_t startLeadWord = 0, startLeadCount = 0xff;
+  uint32_t startFreeWord = 0, startFreeCount = 0xff;
+  // ...and the bytes that may FOLLOW a start byte in an attempt that survives its second step
+  // (leader: the second class; else: not a pure dead end after some start byte, and no start
+  // byte accepts at once).  Same packing; 0xff = no second filter.
+  uint32_t start2LeadWord = 0, start2LeadCount = 0xff;
+  uint32_t start2FreeWord = 0, start2FreeCount = 0xff;
   std::vector<int32_t>  result;   // [nStates]
   std::vector<uint32_t> next;     // [nStates][nClasses], device indices
   std::vector<uint32_t> rawOf;    // [nStates] device index -> state id in the blob

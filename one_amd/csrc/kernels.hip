@@ -151,6 +151,9 @@ struct LaneCtx {
   const uint8_t *leader;  // LDS: class-space leader
   const int32_t *res;     // global: result per device state
   uint32_t init, leaderNext, nPureDead, firstAccept, leaderLen;
+  // start bytes of scan / search attempts (DevDfa): [0] without the leader, [1] with it
+  uint32_t startWord[2] = {0, 0}, startCount[2] = {0xff, 0xff};
+  uint32_t start2Word[2] = {0, 0}, start2Count[2] = {0xff, 0xff};  // ... and of their second bytes
   __device__ __forceinline__ int32_t resultOf(uint32_t s) const {
     return s >= firstAccept ? res[s] : 0;
   }
@@ -180,30 +183,131 @@ __device__ __forceinline__ bool compareThrough(const LaneCtx &c, const uint8_t *
 // Feeds f(byte, index) the bytes p[from..n) in order until it returns false.  The body reads
 // 16-byte aligned chunks (one global_load_dwordx4 per 16 input bytes instead of 16 byte loads);
 // the unaligned head and the tail go byte by byte.
+// Trip sizes: the first trip takes ONE 16-byte chunk (a line that dies in its first bytes -
+// the anchored DFAs that live on these kernels - touches nothing else), every later trip takes
+// up to four, requested back to back: a lane that takes its line 16 bytes at a time comes back
+// to every 128-byte cache line 8 times, and with 64 lanes x 16+ waves per CU the lines are
+// long gone from L1 and L2 by then (measured: ~1 TB/s of HBM-amplified traffic on 256-byte
+// lines whatever the per-byte work; 1.9 TB/s with 64-byte trips).  Chunks are loaded at the
+// line's own alignment (the memory pipeline splits unaligned requests); only the last < 16
+// bytes go byte by byte, so no request reaches past the line.
 template <class F>
 __device__ __forceinline__ void walkBytes(const uint8_t *p, uint64_t from, uint64_t n, F &&f) {
   uint64_t i = from;
-  const uint32_t mis = uint32_t(reinterpret_cast<uintptr_t>(p + i)) & 15u;
-  if (mis) {
-    uint64_t headEnd = i + (16 - mis);
-    if (headEnd > n) headEnd = n;
-    for (; i < headEnd; ++i)
-      if (!f(uint32_t(p[i]), i)) return;
-  }
-  for (; i + 16 <= n; i += 16) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(p + i);
-    // words rolled, bytes unrolled: keeps the body (and its registers) small - these kernels
-    // are latency-bound and live on occupancy
+  uint32_t want = 1;
+  while (i + 16 <= n) {
+    const uint64_t avail = (n - i) >> 4;
+    const uint32_t nc = avail < want ? uint32_t(avail) : want;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    const uint4 b0 = *reinterpret_cast<const uint4 *>(p + i);
+    const uint4 b1 = nc > 1 ? *reinterpret_cast<const uint4 *>(p + i + 16) : z;
+    const uint4 b2 = nc > 2 ? *reinterpret_cast<const uint4 *>(p + i + 32) : z;
+    const uint4 b3 = nc > 3 ? *reinterpret_cast<const uint4 *>(p + i + 48) : z;
 #pragma unroll 1
-    for (int wi = 0; wi < 4; ++wi) {
-      const uint32_t word = wi == 0 ? v.x : wi == 1 ? v.y : wi == 2 ? v.z : v.w;
+    for (uint32_t c = 0; c < nc; ++c) {
+      const uint4 v = c == 0 ? b0 : c == 1 ? b1 : c == 2 ? b2 : b3;
+      // words rolled, bytes unrolled: keeps the body (and its registers) small
+#pragma unroll 1
+      for (int wi = 0; wi < 4; ++wi) {
+        const uint32_t word = wi == 0 ? v.x : wi == 1 ? v.y : wi == 2 ? v.z : v.w;
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (!f((word >> (8 * k)) & 0xffu, i + 4 * wi + k)) return;
+        for (int k = 0; k < 4; ++k)
+          if (!f((word >> (8 * k)) & 0xffu, i + 16 * c + 4 * wi + k)) return;
+      }
     }
+    i += 16ull * nc;
+    want = 4;
   }
   for (; i < n; ++i)
     if (!f(uint32_t(p[i]), i)) return;
+}
+
+// walkBytes that also hands f the NEXT byte (kNoPeek when it is not in the chunk in hand or
+// past the end): scan and search reject almost every start position from two bytes in
+// registers.  A lane that has to go back to memory for a survivor stalls its whole wave, and
+// with one byte of filtering some lane of the 64 survives nearly every step (1 in 47 per lane
+// on text); with two it is 1 in ~2000.
+constexpr uint32_t kNoPeek = 0x100u;
+
+// 0x80 in every byte of `word` that equals one of the `count` (1..4) bytes packed in `set`.
+// Exact SWAR zero-byte test per member: ((x & 0x7f7f7f7f) + 0x7f7f7f7f) | x has the top bit of
+// a byte clear iff that byte of x is zero - no borrow crosses bytes.
+__device__ __forceinline__ uint32_t wordMatchMask(uint32_t word, uint32_t set, uint32_t count) {
+  uint32_t hit = 0;
+  for (uint32_t k = 0; k < count; ++k) {
+    const uint32_t x = word ^ (((set >> (8 * k)) & 0xffu) * 0x01010101u);
+    hit |= ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x);
+  }
+  return hit & 0x80808080u;
+}
+
+// Input words none of whose positions can start a surviving attempt (StartFilter) are stepped
+// over whole - onSkip() stands for the four rejected attempts.  The test is on byte PAIRS where
+// the DFA allows it: what matters is not how rare a candidate is per lane but per WAVE - one
+// lane with a candidate drags all 64 through the per-byte path (on text, a lone 'e' turns up in
+// some lane's word at 99.5 % of the steps; "er" at 11 %).
+struct StartFilter {
+  uint32_t set1, n1;  // start bytes (n1 in 1..4, or 0 = no filter)
+  uint32_t set2, n2;  // bytes that may follow one (0 = no second filter)
+  // scan with the leader: a start byte followed by a wrong second byte makes compareThrough
+  // stop ON that second byte and the outer ++in skip it (Matcher.h:511-518) - if that byte is a
+  // start byte itself, skipping it changes the outcome ("aab" on "aaab"), so such a position
+  // must still be walked: followers that are start bytes count as possible too
+  bool consumes;
+};
+
+template <class S, class F>
+__device__ __forceinline__ void walkBytesPeek(const uint8_t *p, uint64_t from, uint64_t n,
+                                              const StartFilter flt, S &&onSkip, F &&f) {
+  uint64_t i = from;
+  uint32_t want = 1;  // trip sizes as in walkBytes
+  while (i + 16 <= n) {
+    const uint64_t avail = (n - i) >> 4;
+    const uint32_t nc = avail < want ? uint32_t(avail) : want;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    const uint4 b0 = *reinterpret_cast<const uint4 *>(p + i);
+    const uint4 b1 = nc > 1 ? *reinterpret_cast<const uint4 *>(p + i + 16) : z;
+    const uint4 b2 = nc > 2 ? *reinterpret_cast<const uint4 *>(p + i + 32) : z;
+    const uint4 b3 = nc > 3 ? *reinterpret_cast<const uint4 *>(p + i + 48) : z;
+#pragma unroll 1
+    for (uint32_t c = 0; c < nc; ++c) {
+      const uint4 v = c == 0 ? b0 : c == 1 ? b1 : c == 2 ? b2 : b3;
+      const uint32_t after = c == 0 ? b1.x : c == 1 ? b2.x : b3.x;  // first word of the next chunk
+      const bool haveAfter = c + 1 < nc;
+#pragma unroll 1
+      for (int wi = 0; wi < 4; ++wi) {
+        const uint32_t word = wi == 0 ? v.x : wi == 1 ? v.y : wi == 2 ? v.z : v.w;
+        const uint32_t nextWord = wi == 0 ? v.y : wi == 1 ? v.z : wi == 2 ? v.w : after;
+        if (flt.n1) {
+          // positions of this word that can start a surviving attempt: a start byte, followed
+          // (when the follower is in hand) by a byte that may follow one
+          uint32_t cand = wordMatchMask(word, flt.set1, flt.n1);
+          if (cand && flt.n2) {
+            const bool haveNext = wi < 3 || haveAfter;
+            const uint32_t follow = (word >> 8) | (nextWord << 24);
+            uint32_t ok = wordMatchMask(follow, flt.set2, flt.n2);
+            if (flt.consumes) ok |= wordMatchMask(follow, flt.set1, flt.n1);
+            if (!haveNext) ok |= 0x80000000u;  // the last byte's follower is not in hand
+            cand &= ok;
+          }
+          if (!cand) {
+            onSkip();
+            continue;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t nb = k < 3 ? (word >> (8 * (k + 1))) & 0xffu
+                                    : ((wi < 3 || haveAfter) ? nextWord & 0xffu : kNoPeek);
+          if (!f((word >> (8 * k)) & 0xffu, i + 16 * c + 4 * wi + k, nb)) return;
+        }
+      }
+    }
+    i += 16ull * nc;
+    want = 4;
+  }
+  for (; i < n; ++i)
+    if (!f(uint32_t(p[i]), i, kNoPeek)) return;
 }
 
 // include/Matcher.h:363-410
@@ -285,44 +389,94 @@ __device__ int32_t matchLane(const T &tab, const LaneCtx &c, const uint8_t *p, u
   return result;
 }
 
-// include/Matcher.h:498-554
+// include/Matcher.h:498-554.  The start positions are visited through walkBytes (16-byte
+// chunks in registers, one per 16 positions) and almost every one is rejected from the byte in
+// hand: with a leader, when its class is not the leader's first (compareThrough fails at k = 0:
+// the cursor stays put and the loop's ++in moves on - nothing else changes); without one, when
+// the first transition lands on a pure dead end.  Only the survivors touch memory again.
 template <class T>
 __device__ int32_t scanLane(const T &tab, const LaneCtx &c, const uint8_t *p, uint64_t n,
                             int style, bool lead) {
   int32_t result = c.resultOf(c.init);
-  for (uint64_t i = 0; i < n; ++i) {
+  int32_t ret = 0;
+  bool returned = false;
+  uint64_t resume = 0;  // the next start position the reference's outer loop would visit
+  const uint32_t lead0 = lead ? c.leader[0] : 0u;
+  const uint32_t lead1 = lead && c.leaderLen > 1 ? uint32_t(c.leader[1]) : kNoPeek;
+  // no start byte in a word: with the leader nothing changes (compareThrough fails at k = 0),
+  // without it each of the four attempts ends on a dead first step with result = 0
+  const int li = lead ? 1 : 0;
+  const StartFilter flt{c.startWord[li], c.startCount[li] <= 4 ? c.startCount[li] : 0u,
+                        c.start2Word[li], c.start2Count[li] <= 4 ? c.start2Count[li] : 0u, lead};
+  walkBytesPeek(p, 0, n, flt, [&]() { if (!lead) result = 0; },
+                [&](uint32_t byte, uint64_t i, uint32_t nextByte) {
+    if (i < resume) return true;
     uint32_t s;
+    uint64_t q;  // the inner walk reads p[q..n)
+    int32_t prev = 0;
+    bool alive = true;
     if (lead) {
-      if (!compareThrough(c, p, i, n)) continue;  // i sits on the mismatching byte; ++i skips it
+      if (c.eq[byte] != lead0) return true;
+      if (lead1 != kNoPeek && nextByte != kNoPeek && c.eq[nextByte] != lead1) {
+        resume = i + 2;  // compareThrough stops ON the second byte; ++in steps past it
+        return true;
+      }
+      uint64_t j = i;
+      if (!compareThrough(c, p, j, n)) {  // j sits on the mismatching byte; ++in skips it
+        resume = j + 1;
+        return true;
+      }
       s = c.leaderNext;
       result = c.resultOf(s);
-    } else
-      s = c.init;
-    int32_t prev = 0;
-    for (uint64_t q = i; q < n; ++q) {
-      s = tab.next(s, p[q]);
+      q = j;
+      resume = j + 1;
+    } else {
+      // first transition from the byte in hand
+      s = tab.next(c.init, byte);
+      q = i + 1;
+      resume = i + 1;
       if (s >= c.firstAccept) {
         result = c.res[s];
-        if (style == kStyInstant) return result;
-        if (style == kStyFirst) {
-          if (prev && result != prev) return prev;
-          prev = result;
-        }
-        if (style == kStyTangent || style == kStyLast) prev = result;
+        if (style == kStyInstant) { ret = result; returned = true; return false; }
+        prev = result;  // First: prev was 0, so no early return; Tangent / Last: prev = result
+        if (style == kStyFull) prev = 0;
       } else {
         result = 0;
-        if ((style == kStyFirst || style == kStyTangent) && prev > 0) return prev;
-        if (s < c.nPureDead) break;
+        if (s < c.nPureDead) alive = false;
+        // second transition from the byte in hand: most survivors of the first die here
+        else if (nextByte != kNoPeek && tab.next(s, nextByte) < c.nPureDead) alive = false;
       }
     }
-    if (style == kStyLast && result == 0 && prev > 0) return prev;
-    if (result > 0) return result;
-  }
-  return result;
+    if (alive) {
+      for (; q < n; ++q) {
+        s = tab.next(s, p[q]);
+        if (s >= c.firstAccept) {
+          result = c.res[s];
+          if (style == kStyInstant) { ret = result; returned = true; return false; }
+          if (style == kStyFirst) {
+            if (prev && result != prev) { ret = prev; returned = true; return false; }
+            prev = result;
+          }
+          if (style == kStyTangent || style == kStyLast) prev = result;
+        } else {
+          result = 0;
+          if ((style == kStyFirst || style == kStyTangent) && prev > 0) {
+            ret = prev; returned = true; return false;
+          }
+          if (s < c.nPureDead) break;
+        }
+      }
+    }
+    if (style == kStyLast && result == 0 && prev > 0) { ret = prev; returned = true; return false; }
+    if (result > 0) { ret = result; returned = true; return false; }
+    return true;
+  });
+  return returned ? ret : result;
 }
 
 // include/Matcher.h:557-640 searchCore: sliding-window match; the leader is only PEEKED
-// (lookingAt), so no start position is skipped - unlike scanCore
+// (lookingAt), so no start position is skipped - unlike scanCore.  Start positions come
+// through walkBytes and are rejected from the byte in hand like scanLane's.
 template <class T>
 __device__ int32_t searchLane(const T &tab, const LaneCtx &c, const uint8_t *p, uint64_t n,
                               int style, bool lead, uint64_t &startOut, uint64_t &endOut) {
@@ -330,35 +484,62 @@ __device__ int32_t searchLane(const T &tab, const LaneCtx &c, const uint8_t *p, 
   endOut = 0;
   int32_t result = c.resultOf(c.init);
   uint64_t matchStart = 0, matchEnd = 0;
-  for (uint64_t idx = 0; idx < n; ++idx) {
-    if (lead && !lookingAt(c, p, idx, n)) continue;
-    uint32_t s = c.init;
+  const uint32_t lead0 = lead ? c.leader[0] : 0u;
+  const uint32_t lead1 = lead && c.leaderLen > 1 ? uint32_t(c.leader[1]) : kNoPeek;
+  const int li = lead ? 1 : 0;
+  const StartFilter flt{c.startWord[li], c.startCount[li] <= 4 ? c.startCount[li] : 0u,
+                        c.start2Word[li], c.start2Count[li] <= 4 ? c.start2Count[li] : 0u, false};
+  walkBytesPeek(p, 0, n, flt, [&]() { if (!lead) result = 0; },
+                [&](uint32_t byte, uint64_t idx, uint32_t nextByte) {
+    if (lead) {
+      if (c.eq[byte] != lead0) return true;
+      if (lead1 != kNoPeek && nextByte != kNoPeek && c.eq[nextByte] != lead1) return true;
+      if (!lookingAt(c, p, idx, n)) return true;
+    }
+    // first transition from the byte in hand (:589-600 with q == idx)
+    uint32_t s = tab.next(c.init, byte);
     int32_t prev = 0;
-    matchStart = idx;
+    matchStart = idx;  // set at the top of the attempt, and again if the step leaves init
     matchEnd = idx;
-    for (uint64_t q = idx; q < n; ++q) {
-      const uint32_t was = s;
-      s = tab.next(s, p[q]);
-      if (was == c.init && s != was) matchStart = q;
-      if (s >= c.firstAccept) {
-        result = c.res[s];
-        if (style == kStyFirst) {
-          if (prev && result != prev) { result = prev; break; }
-          prev = result;
+    bool walk = true;
+    if (s >= c.firstAccept) {
+      result = c.res[s];
+      if (style == kStyFirst) prev = result;
+      matchEnd = idx + 1;
+      if (style == kStyInstant) walk = false;
+      if (style == kStyTangent || style == kStyLast) prev = result;
+    } else {
+      result = 0;
+      if (s < c.nPureDead) walk = false;
+      // second transition from the byte in hand (a non-accepting dead end leaves result 0 and
+      // the positions are only reported for a positive result)
+      else if (nextByte != kNoPeek && tab.next(s, nextByte) < c.nPureDead) walk = false;
+    }
+    if (walk) {
+      for (uint64_t q = idx + 1; q < n; ++q) {
+        const uint32_t was = s;
+        s = tab.next(s, p[q]);
+        if (was == c.init && s != was) matchStart = q;
+        if (s >= c.firstAccept) {
+          result = c.res[s];
+          if (style == kStyFirst) {
+            if (prev && result != prev) { result = prev; break; }
+            prev = result;
+          }
+          matchEnd = q + 1;
+          if (style == kStyInstant) break;
+          if (style == kStyTangent || style == kStyLast) prev = result;
+        } else {
+          result = 0;
+          if (style == kStyFirst && prev > 0) { result = prev; break; }
+          if (style == kStyTangent && prev > 0) break;
+          if (s < c.nPureDead) break;
         }
-        matchEnd = q + 1;
-        if (style == kStyInstant) break;
-        if (style == kStyTangent || style == kStyLast) prev = result;
-      } else {
-        result = 0;
-        if (style == kStyFirst && prev > 0) { result = prev; break; }
-        if (style == kStyTangent && prev > 0) break;
-        if (s < c.nPureDead) break;
       }
     }
     if ((style == kStyTangent || style == kStyLast) && result == 0 && prev > 0) result = prev;
-    if (result > 0) break;
-  }
+    return !(result > 0);
+  });
   if (result != 0) {
     startOut = matchStart;
     endOut = matchEnd;
@@ -368,15 +549,22 @@ __device__ int32_t searchLane(const T &tab, const LaneCtx &c, const uint8_t *p, 
 
 // dynamic LDS: [equiv 256][leader 256][table (LDS kinds only)].  An LDS-resident table is
 // shared by one 1024-thread workgroup per CU; a table in HBM/L2 runs 256-thread workgroups.
-template <int KIND, int kGenericThreads>
+// One instantiation per verb: the four lane functions together need twice the registers any
+// one of them does.
+template <int KIND, int kGenericThreads, int VERB>
 __global__ void __launch_bounds__(kGenericThreads)
-k_generic(DevDfa d, Batch b, int verb, int style, int lead) {
+k_generic(DevDfa d, Batch b, int style, int lead) {
+  constexpr int verb = VERB;
   extern __shared__ __align__(16) uint8_t lds[];
   uint8_t *eq = lds;
   uint8_t *leader = lds + 256;
   const Tab<KIND> tab = stageTab<KIND, kGenericThreads>(d, lds);
   LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
             d.leaderLen};
+  c.startWord[0] = d.startFreeWord; c.startCount[0] = d.startFreeCount;
+  c.startWord[1] = d.startLeadWord; c.startCount[1] = d.startLeadCount;
+  c.start2Word[0] = d.start2FreeWord; c.start2Count[0] = d.start2FreeCount;
+  c.start2Word[1] = d.start2LeadWord; c.start2Count[1] = d.start2LeadCount;
 
   const uint64_t step = uint64_t(gridDim.x) * kGenericThreads;
   for (uint64_t line = uint64_t(blockIdx.x) * kGenericThreads + threadIdx.x; line < b.n;
@@ -603,6 +791,10 @@ k_collect(DevDfa d, Batch b, uint64_t cap, uint64_t *counts) {
   const Tab<KIND> tab = stageTab<KIND, kThreads>(d, lds);
   LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
             d.leaderLen};
+  c.startWord[0] = d.startFreeWord; c.startCount[0] = d.startFreeCount;
+  c.startWord[1] = d.startLeadWord; c.startCount[1] = d.startLeadCount;
+  c.start2Word[0] = d.start2FreeWord; c.start2Count[0] = d.start2FreeCount;
+  c.start2Word[1] = d.start2LeadWord; c.start2Count[1] = d.start2LeadCount;
   const uint64_t step = uint64_t(gridDim.x) * kThreads;
   for (uint64_t line = uint64_t(blockIdx.x) * kThreads + threadIdx.x; line < b.n; line += step) {
     const uint8_t *p;
@@ -683,6 +875,10 @@ k_matchall(DevDfa d, Batch b, uint64_t cap, uint64_t *counts, int lead) {
   const Tab<KIND> tab = stageTab<KIND, kThreads>(d, lds);
   LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
             d.leaderLen};
+  c.startWord[0] = d.startFreeWord; c.startCount[0] = d.startFreeCount;
+  c.startWord[1] = d.startLeadWord; c.startCount[1] = d.startLeadCount;
+  c.start2Word[0] = d.start2FreeWord; c.start2Count[0] = d.start2FreeCount;
+  c.start2Word[1] = d.start2LeadWord; c.start2Count[1] = d.start2LeadCount;
   const uint64_t step = uint64_t(gridDim.x) * kThreads;
   for (uint64_t line = uint64_t(blockIdx.x) * kThreads + threadIdx.x; line < b.n; line += step) {
     const uint8_t *p;
@@ -716,6 +912,10 @@ k_advance(DevDfa d, Batch b, uint32_t *state) {
   const Tab<KIND> tab = stageTab<KIND, kThreads>(d, lds);
   LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
             d.leaderLen};
+  c.startWord[0] = d.startFreeWord; c.startCount[0] = d.startFreeCount;
+  c.startWord[1] = d.startLeadWord; c.startCount[1] = d.startLeadCount;
+  c.start2Word[0] = d.start2FreeWord; c.start2Count[0] = d.start2FreeCount;
+  c.start2Word[1] = d.start2LeadWord; c.start2Count[1] = d.start2LeadCount;
   const uint64_t step = uint64_t(gridDim.x) * kThreads;
   for (uint64_t line = uint64_t(blockIdx.x) * kThreads + threadIdx.x; line < b.n; line += step) {
     const uint8_t *p;
@@ -806,6 +1006,10 @@ k_replace(DevDfa d, Batch b, int style, int lead, const uint8_t *repl, uint64_t 
   const Tab<KIND> tab = stageTab<KIND, kThreads>(d, lds);
   LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
             d.leaderLen};
+  c.startWord[0] = d.startFreeWord; c.startCount[0] = d.startFreeCount;
+  c.startWord[1] = d.startLeadWord; c.startCount[1] = d.startLeadCount;
+  c.start2Word[0] = d.start2FreeWord; c.start2Count[0] = d.start2FreeCount;
+  c.start2Word[1] = d.start2LeadWord; c.start2Count[1] = d.start2LeadCount;
   const uint64_t step = uint64_t(gridDim.x) * kThreads;
   for (uint64_t line = uint64_t(blockIdx.x) * kThreads + threadIdx.x; line < b.n; line += step) {
     const uint8_t *p;
@@ -1070,16 +1274,26 @@ hipError_t launchGeneric(const DevDfa &d, const Batch &b, int verb, int style, i
   constexpr bool kLds = Tab<KIND>::kInLds || KIND == REDGPU_TAB_HOT_ROWS;
   constexpr int kThreads = kLds ? 1024 : 256;
   const size_t ldsBytes = 512 + ldsTableBytes<KIND>(d);
-  hipError_t e = setLds(k_generic<KIND, kThreads>, ldsBytes);
-  if (e != hipSuccess) return e;
   uint64_t blocks = (b.n + kThreads - 1) / kThreads;
   // an LDS-resident table is re-staged per block: keep the grid near one wave of blocks
   const uint64_t perCu = kLds ? (ldsBytes <= 80 * 1024 ? 2 : 1) : 8;
   const uint64_t cap = uint64_t(cfg.numCUs) * perCu;
   if (blocks > cap) blocks = cap;
   if (blocks == 0) blocks = 1;
-  hipLaunchKernelGGL((k_generic<KIND, kThreads>), dim3(uint32_t(blocks)), dim3(kThreads),
-                     ldsBytes, stream, d, b, verb, style, lead);
+#define GEN_LAUNCH(V)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = setLds(k_generic<KIND, kThreads, V>, ldsBytes);                          \
+    if (e_ != hipSuccess) return e_;                                                         \
+    hipLaunchKernelGGL((k_generic<KIND, kThreads, V>), dim3(uint32_t(blocks)), dim3(kThreads), \
+                       ldsBytes, stream, d, b, style, lead);                                 \
+  } while (0)
+  switch (verb) {
+  case kCheck: GEN_LAUNCH(kCheck); break;
+  case kScan: GEN_LAUNCH(kScan); break;
+  case kSearch: GEN_LAUNCH(kSearch); break;
+  default: GEN_LAUNCH(kMatch); break;
+  }
+#undef GEN_LAUNCH
   return hipGetLastError();
 }
 

@@ -250,6 +250,14 @@ int uploadImage(SharedImage *im) {
   d.hot8Off = img.hot8Off;
   d.hotShift = img.hotShift;
   d.earlyDeath = img.earlyDeath ? 1 : 0;
+  d.startLeadWord = img.startLeadWord;
+  d.startLeadCount = img.startLeadCount;
+  d.startFreeWord = img.startFreeWord;
+  d.startFreeCount = img.startFreeCount;
+  d.start2LeadWord = img.start2LeadWord;
+  d.start2LeadCount = img.start2LeadCount;
+  d.start2FreeWord = img.start2FreeWord;
+  d.start2FreeCount = img.start2FreeCount;
   return REDGPU_OK;
 }
 

@@ -265,6 +265,7 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
       p.swap(q);
     }
     if (measured && measured->size() == stateCnt) {
+      img.tuned = true;
       // observed visits decide; the model (scaled far below one observed visit) breaks ties
       double msum = 0.0, vsum = 0.0;
       for (uint32_t s : reach) { msum += (*measured)[s]; vsum += visits[s]; }

@@ -66,6 +66,7 @@ struct DfaImage {
   // so that the hot set is ONE index range that straddles firstAccept.
   uint32_t hotLo = 0, nHot = 0, hot8Off = 0, hotShift = 0;
   uint32_t hotCoveragePpm = 0;    // modelled share of visits landing on hot rows
+  bool     tuned = false;         // the hot rows were ranked by observed visits (redgpu_dfa_tune)
   bool     earlyDeath = false;    // the model's walk is in a pure dead end within 16 bytes
                                   // more often than not (anchored DFA on arbitrary text)
 };

@@ -117,7 +117,46 @@ __device__ __forceinline__ uint32_t waveMaxU32(uint32_t v) {
   return uint32_t(__builtin_amdgcn_readfirstlane(int(v)));
 }
 
+// HOT (REDGPU_TAB_HOT_ROWS DFAs; see k_stream.h): the lanes found in the sink after a 64-byte
+// block re-walk the block's `rem` valid bytes from its saved entry state - hot steps through the
+// LDS table, cold ones through the class table - with the bookkeeping in global state ids.
 template <int MODE>
+__device__ __noinline__ SlowBook slowRagged(const DevDfa &d, const uint8_t *tab8, const uint8_t *p,
+                                            uint32_t off, uint32_t rem, SlowBook in) {
+  uint32_t st = in.st, accS = in.accS, endv = in.endv, startv = in.startv;
+  constexpr bool kAcc = MODE == kSmLastStartEnd || MODE == kSmLastEnd;
+  constexpr bool kStart = MODE == kSmLastStartEnd || MODE == kSmFullStart;
+  const uint16_t *cls = reinterpret_cast<const uint16_t *>(d.table);
+  const uint8_t *eq = d.equivLeader;
+  // four 16-byte requests (the whole block is readable: k_ragged read it from here), then
+  // `rem` steps
+#pragma unroll 1
+  for (uint32_t c4 = 0; c4 < 4 && 16 * c4 < rem; ++c4) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(p + 16 * c4);
+#pragma unroll 1
+    for (uint32_t wi = 0; wi < 4; ++wi) {
+      const uint32_t word = wi == 0 ? v.x : wi == 1 ? v.y : wi == 2 ? v.z : v.w;
+#pragma unroll 1
+      for (uint32_t kb = 0; kb < 4; ++kb) {
+        const uint32_t k = 16 * c4 + 4 * wi + kb;
+        if (k >= rem) break;
+        const uint32_t byte = (word >> (8 * kb)) & 0xffu;
+        const uint32_t was = st;
+        const uint32_t hr = st - d.hotLo;
+        const uint32_t nx = hr < d.nHot ? uint32_t(tab8[((hr + d.hotShift) << 8) | byte]) : 255u;
+        if (nx != 255u)
+          st = (d.hotShift && nx == 0) ? 0u : d.hotLo + nx - d.hotShift;
+        else
+          st = cls[size_t(st) * d.nClasses + eq[byte]];
+        if (kStart && was == d.init && st != was) startv = off + k;
+        if (kAcc && st >= d.firstAccept) { accS = st; endv = off + k + 1; }
+      }
+    }
+  }
+  return SlowBook{st, accS, endv, startv};
+}
+
+template <int MODE, bool HOT = false>
 __global__ void __launch_bounds__(kStreamThreads)
 k_ragged(DevDfa d, Batch io) {
   constexpr int CH = kStreamChains;
@@ -128,20 +167,30 @@ k_ragged(DevDfa d, Batch io) {
   uint8_t *tab = lds;
   int32_t *ldsRes = reinterpret_cast<int32_t *>(lds + kStreamTabBytes);
 
-  const uint32_t init = d.init, firstAccept = d.firstAccept;
+  // HOT: the walk runs in hot-index space (k_stream.h)
+  const uint32_t init =
+      HOT ? (d.init - d.hotLo < d.nHot ? d.init - d.hotLo + d.hotShift : 0x1ffu) : d.init;
+  const uint32_t firstAccept = HOT ? d.firstAccept - d.hotLo + d.hotShift : d.firstAccept;
+  auto toHot = [&](uint32_t st) -> uint32_t {
+    if (d.hotShift && st < d.nPureDead) return 0u;
+    return st - d.hotLo < d.nHot ? st - d.hotLo + d.hotShift : 255u;
+  };
+  auto toGlobal = [&](uint32_t idx) -> uint32_t {
+    return (d.hotShift && idx == 0) ? 0u : d.hotLo + idx - d.hotShift;
+  };
   const uint64_t linesPerTile = uint64_t(THREADS) * CH;
   const uint64_t nTiles = (io.n + linesPerTile - 1) / linesPerTile;
   if (blockIdx.x >= nTiles) return;
   {
-    const uint4 *src = reinterpret_cast<const uint4 *>(d.table);
-    const uint32_t n16 = d.tableBytes / 16;
+    const uint4 *src = reinterpret_cast<const uint4 *>(d.table + (HOT ? d.hot8Off : 0u));
+    const uint32_t n16 = HOT ? kStreamTabBytes / 16 : d.tableBytes / 16;
     uint4 v[kStreamTabBytes / 16 / THREADS];
 #pragma unroll
     for (uint32_t k = 0; k < kStreamTabBytes / 16 / THREADS; ++k) {
       const uint32_t i = k * THREADS + threadIdx.x;
       v[k] = i < n16 ? src[i] : make_uint4(0, 0, 0, 0);
     }
-    const int32_t myRes = threadIdx.x < d.nStates ? d.result[threadIdx.x] : 0;
+    const int32_t myRes = HOT ? 0 : threadIdx.x < d.nStates ? d.result[threadIdx.x] : 0;
     uint4 *dst = reinterpret_cast<uint4 *>(tab);
 #pragma unroll
     for (uint32_t k = 0; k < kStreamTabBytes / 16 / THREADS; ++k) dst[k * THREADS + threadIdx.x] = v[k];
@@ -153,7 +202,8 @@ k_ragged(DevDfa d, Batch io) {
   const uint64_t padStart = total >= 128 ? total - 128 : 0;  // pad[] = data[padStart, total) + 0s
   // the bucketing pass's verdict sits right behind the permutation
   const bool usePerm = io.perm && io.perm[io.n] != 0;
-  const int32_t initResult = init >= firstAccept ? ldsRes[init] : 0;
+  const int32_t initResult = HOT ? (d.init >= d.firstAccept ? d.result[d.init] : 0)
+                                 : (init >= firstAccept ? ldsRes[init] : 0);
 
   for (uint64_t tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
     uint64_t lineOff[CH];
@@ -183,11 +233,14 @@ k_ragged(DevDfa d, Batch io) {
     const uint32_t R = waveMaxU32(blocksWanted);  // this WAVE's trip count
 
     uint32_t s[CH], accS[CH], endv[CH], startv[CH];
+    uint32_t g[CH];  // HOT: global id of the lane's state while it is outside the hot set
     uint64_t mA[CH], mB[CH], vA[CH], vB[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       s[c] = init; accS[c] = 0; endv[c] = 0; startv[c] = 0;
       mA[c] = ~0ull; mB[c] = ~0ull; vA[c] = ~0ull; vB[c] = ~0ull;
+      g[c] = kNoState;
+      if (HOT && init == 0x1ffu) { s[c] = 255u; g[c] = d.init; }
     }
 
     BlockRegs<1> A[CH], B[CH];
@@ -206,11 +259,13 @@ k_ragged(DevDfa d, Batch io) {
     auto walk = [&](const BlockRegs<1> (&blk)[CH], uint32_t r) {
       uint32_t rem[CH];
       StreamBook b[CH];
+      uint32_t s0[CH];  // HOT: the block's entry state (hot index), for the re-walk
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
         const uint32_t done = r * 64;
         rem[c] = len[c] > done ? (len[c] - done > 64 ? 64 : len[c] - done) : 0;
-        b[c].acc = accS[c]; b[c].end = 0; b[c].start = 0;
+        b[c].acc = HOT ? 0u : accS[c]; b[c].end = 0; b[c].start = 0;
+        s0[c] = s[c];
       }
       uint4 piece[CH];
 #pragma unroll
@@ -228,13 +283,39 @@ k_ragged(DevDfa d, Batch io) {
       // fold (as k_stream); the state after the block's 64th byte counts only if that byte
       // was part of the line (rem == 64) - vA holds "step 63 was valid" for exactly that
       const uint32_t off = r * 64;
+      bool redo[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) redo[c] = HOT && rem[c] != 0 && s[c] == 255u;
+      if (HOT && __builtin_amdgcn_ballot_w64(redo[0] || redo[CH - 1])) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          if (redo[c]) {
+            const uint64_t bo = lineOff[c] + uint64_t(off);
+            const uint8_t *src = bo + 64 <= total ? io.data + bo : io.pad + (bo - padStart);
+            const SlowBook o = slowRagged<MODE>(
+                d, tab, src, off, rem[c],
+                SlowBook{g[c] != kNoState ? g[c] : toGlobal(s0[c]), accS[c], endv[c], startv[c]});
+            accS[c] = o.accS; endv[c] = o.endv; startv[c] = o.startv;
+            s[c] = toHot(o.st);
+            g[c] = s[c] != 255u ? kNoState : o.st;
+          }
+        }
+      }
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
+        if (HOT && redo[c]) continue;
         const bool full = rem[c] == 64;
-        if (kAcc) {
+        if (kAcc && !HOT) {
           accS[c] = b[c].acc;
           endv[c] = b[c].end ? off + b[c].end : endv[c];
           if (full && s[c] >= firstAccept) { accS[c] = s[c]; endv[c] = off + 64; }
+        }
+        if (kAcc && HOT) {
+          if (b[c].end) { accS[c] = toGlobal(b[c].acc); endv[c] = off + b[c].end; }
+          if (full && s[c] >= firstAccept && s[c] != 255u) {
+            accS[c] = toGlobal(s[c]);
+            endv[c] = off + 64;
+          }
         }
         if (kStart) {
           startv[c] = b[c].start ? off + b[c].start - 1 : startv[c];
@@ -262,8 +343,12 @@ k_ragged(DevDfa d, Batch io) {
         en = 0;
         startv[c] = 0;
       } else if (kAcc) {
-        rr = endv[c] ? ldsRes[accS[c]] : 0;
+        rr = endv[c] ? (HOT ? d.result[accS[c]] : ldsRes[accS[c]]) : 0;
         en = endv[c];
+      } else if (HOT) {
+        const uint32_t sG = g[c] != kNoState ? g[c] : toGlobal(s[c]);
+        rr = sG >= d.firstAccept ? d.result[sG] : 0;
+        en = len[c];
       } else {
         rr = s[c] >= firstAccept ? ldsRes[s[c]] : 0;
         en = len[c];
@@ -444,7 +529,7 @@ k_tail_pad(const uint8_t *data, const uint64_t *offsets, uint64_t n, uint8_t *pa
   pad[threadIdx.x] = i < total ? data[i] : uint8_t(0);
 }
 
-template <int MODE>
+template <int MODE, bool HOT = false>
 hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
                          hipStream_t stream) {
   const uint64_t linesPerTile = uint64_t(kStreamThreads) * kStreamChains;
@@ -473,6 +558,7 @@ hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
   } else {
     hipLaunchKernelGGL(k_tail_pad, dim3(1), dim3(192), 0, stream, b.data, b.offsets, b.n, pad);
   }
-  hipLaunchKernelGGL(k_ragged<MODE>, dim3(uint32_t(blocks)), dim3(kStreamThreads), 0, stream, d, rb);
+  hipLaunchKernelGGL((k_ragged<MODE, HOT>), dim3(uint32_t(blocks)), dim3(kStreamThreads), 0, stream,
+                     d, rb);
   return hipGetLastError();
 }

@@ -159,17 +159,29 @@ __device__ __noinline__ SlowBook slowHalf(const DevDfa &d, const uint8_t *tab8, 
   constexpr bool kStart = MODE == kSmLastStartEnd || MODE == kSmFullStart;
   const uint16_t *cls = reinterpret_cast<const uint16_t *>(d.table);
   const uint8_t *eq = d.equivLeader;
-  for (uint32_t k = 0; k < 64; ++k) {
-    const uint32_t byte = p[k];
-    const uint32_t was = st;
-    const uint32_t hr = st - d.hotLo;
-    const uint32_t nx = hr < d.nHot ? uint32_t(tab8[((hr + d.hotShift) << 8) | byte]) : 255u;
-    if (nx != 255u)
-      st = (d.hotShift && nx == 0) ? 0u : d.hotLo + nx - d.hotShift;
-    else
-      st = cls[size_t(st) * d.nClasses + eq[byte]];
-    if (kStart && was == d.init && st != was) startv = off + k;
-    if (kAcc && st >= d.firstAccept) { accS = st; endv = off + k + 1; }
+  // the block comes back in four 16-byte requests (it is still in L1/L2), not 64 byte loads:
+  // the lanes waiting on this one pay for every round trip
+#pragma unroll 1
+  for (uint32_t c4 = 0; c4 < 4; ++c4) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(p + 16 * c4);
+#pragma unroll 1
+    for (uint32_t wi = 0; wi < 4; ++wi) {
+      const uint32_t word = wi == 0 ? v.x : wi == 1 ? v.y : wi == 2 ? v.z : v.w;
+#pragma unroll 1
+      for (uint32_t kb = 0; kb < 4; ++kb) {
+        const uint32_t k = 16 * c4 + 4 * wi + kb;
+        const uint32_t byte = (word >> (8 * kb)) & 0xffu;
+        const uint32_t was = st;
+        const uint32_t hr = st - d.hotLo;
+        const uint32_t nx = hr < d.nHot ? uint32_t(tab8[((hr + d.hotShift) << 8) | byte]) : 255u;
+        if (nx != 255u)
+          st = (d.hotShift && nx == 0) ? 0u : d.hotLo + nx - d.hotShift;
+        else
+          st = cls[size_t(st) * d.nClasses + eq[byte]];
+        if (kStart && was == d.init && st != was) startv = off + k;
+        if (kAcc && st >= d.firstAccept) { accS = st; endv = off + k + 1; }
+      }
+    }
   }
   return SlowBook{st, accS, endv, startv};
 }

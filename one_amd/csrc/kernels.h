@@ -28,6 +28,7 @@ struct DevDfa {
   // [hot index][byte] u8 table at table + hot8Off, hot index = s - hotLo + hotShift
   uint32_t hotLo, nHot, hot8Off, hotShift;
   uint32_t earlyDeath;           // the visit model sees walks die within 16 bytes
+  uint32_t tuned;                // hot rows ranked by observed visits
   // start bytes for scan / search (dfa_image.h): packed members, count (0xff = no filter)
   uint32_t startLeadWord, startLeadCount, startFreeWord, startFreeCount;
   uint32_t start2LeadWord, start2LeadCount, start2FreeWord, start2FreeCount;

@@ -1698,6 +1698,29 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
     return e;
   }
 
+  // ... and the same for DFAs too big for LDS (hot rows, cold excursions re-walked per block) -
+  // once the hot rows have been ranked on real input (redgpu_dfa_tune).  On ragged text matches
+  // sit at any offset, so with the create-time model's ranking some lane of a wave is in a cold
+  // excursion in nearly every block and the 8 waves of this kernel cannot hide the re-walks
+  // (measured, URI-V6 on text with a URL every ~8 lines: 128 GB/s untuned, 556 GB/s tuned,
+  // ~600 GB/s through k_generic's 32 waves either way); without URLs 0.63-1.2 TB/s.
+  const bool hotRaggedOk = !cfg.forceGeneric && !dying && hotStreamEligible(d) && b.offsets &&
+                           (d.tuned || cfg.forceStream) &&
+                           (verb == kCheck || verb == kMatch) &&
+                           (style == kStyLast || style == kStyFull) && !lead;
+  if (hotRaggedOk) {
+    Batch sb = b;
+    if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
+    if (style == kStyLast) {
+      if (sb.start) { *kernelName = "k_ragged<last,start,end,hot>"; return launchRaggedT<kSmLastStartEnd, true>(d, sb, cfg, stream); }
+      *kernelName = "k_ragged<last,end,hot>";
+      return launchRaggedT<kSmLastEnd, true>(d, sb, cfg, stream);
+    }
+    if (sb.start) { *kernelName = "k_ragged<full,start,hot>"; return launchRaggedT<kSmFullStart, true>(d, sb, cfg, stream); }
+    *kernelName = "k_ragged<full,hot>";
+    return launchRaggedT<kSmFull, true>(d, sb, cfg, stream);
+  }
+
   *kernelName = "k_generic";
   switch (d.tableKind) {
   case REDGPU_TAB_LDS_FUSED_U8:

@@ -250,6 +250,7 @@ int uploadImage(SharedImage *im) {
   d.hot8Off = img.hot8Off;
   d.hotShift = img.hotShift;
   d.earlyDeath = img.earlyDeath ? 1 : 0;
+  d.tuned = img.tuned ? 1 : 0;
   d.startLeadWord = img.startLeadWord;
   d.startLeadCount = img.startLeadCount;
   d.startFreeWord = img.startFreeWord;

@@ -22,3 +22,20 @@ for dd, oo, label in ((d, o, "uniform"), (d2, o2, "geometric")):
     b.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 10
     print(label, "%.1f us  %.1f GB/s" % (ms * 1e3, dd.numel() / ms / 1e6), one_amd.last_kernel(), flush=True)
+# big real-regex DFA (hot rows) on the same geometric text lines, untuned and tuned
+if len(sys.argv) > 1 and sys.argv[1] == "uri_v6":
+    t = W.alphabet_bytes(int(off2[-1]), 19).copy()
+    for k in range(0, t.size - 100, 1200):
+        t[k:k + len(W.URI_PLANT)] = np.frombuffer(W.URI_PLANT, dtype=np.uint8)
+    d3 = torch.from_numpy(t).cuda()
+    for label in ("untuned", "tuned"):
+        if label == "tuned":
+            exe.tune(d3[: int(off2[1 << 14])], offsets=o2[: (1 << 14) + 1].contiguous())
+        for _ in range(3): one_amd.match_batch(exe, d3, 4, 0, offsets=o2)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10): one_amd.match_batch(exe, d3, 4, 0, offsets=o2)
+        b.record(); torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 10
+        print("geometric text + https URLs,", label, "%.1f us  %.1f GB/s" % (ms * 1e3, d3.numel() / ms / 1e6), one_amd.last_kernel(), flush=True)

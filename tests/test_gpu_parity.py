@@ -271,6 +271,49 @@ def test_hot_row_streaming_kernel_vs_oracle(case):
         assert np.array_equal(res, cpu.advance_batch(data, ostate, stride=L, n=n))
 
 
+@pytest.mark.parametrize("case", ["uri_v6_text", "uri_v6_random", "random_cold", "random_cold_dead"])
+def test_hot_row_ragged_kernel_vs_oracle(case):
+    """k_ragged<.., hot>: ragged lines over a DFA too big for LDS - all-hot walks, walks with cold
+    excursions (planted URLs), and a dense random DFA with 40 forced hot rows where nearly every
+    block is re-walked; every mode; empty lines, lines ending at the very end of the buffer, a
+    few long lines; with and without the length-bucketing pass (20000 lines)."""
+    rng = np.random.default_rng(21)
+    if case.startswith("random_cold"):
+        blob = random_dfa(2500, 48, 79, dead_frac=0.004 if case.endswith("dead") else 0.0,
+                          accept_frac=0.2)
+        kw = dict(force_hot=True, lds_table_max=40 * 256, force_stream=True)
+        gen = W.random_bytes
+    else:
+        blob = load_dfa("uri_v6")
+        kw = dict(force_stream=True)   # untuned handles keep k_generic on ragged lines by default
+        gen = W.random_bytes if case.endswith("random") else W.alphabet_bytes
+    cpu = O.CpuOracle(blob)
+    for n in (3000, 20000):
+        lens = rng.geometric(1 / 90, n).astype(np.int64) - 1
+        lens[rng.integers(0, n, 5)] = rng.integers(2000, 5000, 5)
+        offsets = np.zeros(n + 1, dtype=np.uint64)
+        offsets[1:] = np.cumsum(lens)
+        data = gen(int(offsets[-1]), 31 + n).copy()
+        if case == "uri_v6_text":
+            for k in range(0, data.size - 100, 700):
+                plant = W.URI_V6_PLANT if (k // 700) % 3 == 0 else W.URI_PLANT
+                data[k:k + len(plant)] = np.frombuffer(plant, dtype=np.uint8)
+        for extra in ({}, {"no_bucketing": True}):
+            exe = one_amd.Executable(blob, **kw, **extra)
+            assert exe.info["table_kind"] == 6
+            for sty in (4, 5):
+                er, es, ee = cpu.batch("match", sty, 0, data, offsets=offsets, threads=8)
+                r, s, e = one_amd.match_batch(exe, data, sty, 0, offsets=offsets)
+                assert one_amd.last_kernel().startswith("k_ragged<") and \
+                    one_amd.last_kernel().endswith("hot>"), one_amd.last_kernel()
+                assert np.array_equal(r, er), (case, n, sty)
+                assert np.array_equal(s, es) and np.array_equal(e, ee), (case, n, sty)
+                r, _, e = one_amd.match_batch(exe, data, sty, 0, offsets=offsets, want_start=False)
+                assert np.array_equal(r, er) and np.array_equal(e, ee)
+                assert np.array_equal(one_amd.check_batch(exe, data, sty, 0, offsets=offsets),
+                                      cpu.batch("check", sty, 0, data, offsets=offsets, threads=8)[0])
+
+
 def test_tune_reranks_hot_rows_results_unchanged():
     """redgpu_dfa_tune: visits counted on a sample of URL-bearing text re-rank the hot rows;
     outputs stay bit-exact, the share of the walk served from LDS goes up (measured on held-out
@@ -295,6 +338,21 @@ def test_tune_reranks_hot_rows_results_unchanged():
         r, s, e = fn(exe, vec["data"], 4, 0, offsets=vec["offsets"])
         assert np.array_equal(r, vec[verb + "_4_0_res"]) and np.array_equal(e, vec[verb + "_4_0_end"])
         assert np.array_equal(s, vec[verb + "_4_0_start"])
+    # ragged lines: the tuned handle takes k_ragged<..,hot>, an untuned one stays with k_generic
+    rng = np.random.default_rng(4)
+    lens = rng.integers(0, 300, 5000)
+    roff = np.zeros(len(lens) + 1, dtype=np.uint64)
+    roff[1:] = np.cumsum(lens)
+    rdata = held[: int(roff[-1])]
+    rexp = cpu.batch("match", 4, 0, rdata, offsets=roff, threads=8)
+    got = one_amd.match_batch(exe, rdata, 4, 0, offsets=roff)
+    assert one_amd.last_kernel() == "k_ragged<last,start,end,hot>"
+    for g, e in zip(got, rexp):
+        assert np.array_equal(g, e)
+    got = one_amd.match_batch(one_amd.Executable(blob), rdata, 4, 0, offsets=roff)
+    assert one_amd.last_kernel() == "k_generic"
+    for g, e in zip(got, rexp):
+        assert np.array_equal(g, e)
     # StatefulMatcher: after tuning, whole lines in one chunk reproduce check<styFull>
     state = np.full(n, one_amd.STATE_INITIAL, dtype=np.uint32)
     res = one_amd.advance_batch(exe, held, state, stride=L, n=n)

@@ -1698,14 +1698,13 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
     return e;
   }
 
-  // ... and the same for DFAs too big for LDS (hot rows, cold excursions re-walked per block) -
-  // once the hot rows have been ranked on real input (redgpu_dfa_tune).  On ragged text matches
-  // sit at any offset, so with the create-time model's ranking some lane of a wave is in a cold
-  // excursion in nearly every block and the 8 waves of this kernel cannot hide the re-walks
-  // (measured, URI-V6 on text with a URL every ~8 lines: 128 GB/s untuned, 556 GB/s tuned,
-  // ~600 GB/s through k_generic's 32 waves either way); without URLs 0.63-1.2 TB/s.
+  // ... and the same for DFAs too big for LDS (hot rows, cold excursions re-walked per block).
+  // On ragged text matches sit at any offset, so with the create-time ranking some lane of a
+  // wave is in a cold excursion in nearly every block and the re-walks dominate (URI-V6 on
+  // geometric-length text with a URL every ~8 lines: 128 GB/s untuned, 556 GB/s after
+  // redgpu_dfa_tune) - still ahead of k_generic on the same lines (98 GB/s: its one-line-per-
+  // lane walk also pays the wave-max of the line lengths); without URLs 629 vs 107 GB/s.
   const bool hotRaggedOk = !cfg.forceGeneric && !dying && hotStreamEligible(d) && b.offsets &&
-                           (d.tuned || cfg.forceStream) &&
                            (verb == kCheck || verb == kMatch) &&
                            (style == kStyLast || style == kStyFull) && !lead;
   if (hotRaggedOk) {

@@ -281,11 +281,11 @@ def test_hot_row_ragged_kernel_vs_oracle(case):
     if case.startswith("random_cold"):
         blob = random_dfa(2500, 48, 79, dead_frac=0.004 if case.endswith("dead") else 0.0,
                           accept_frac=0.2)
-        kw = dict(force_hot=True, lds_table_max=40 * 256, force_stream=True)
+        kw = dict(force_hot=True, lds_table_max=40 * 256)
         gen = W.random_bytes
     else:
         blob = load_dfa("uri_v6")
-        kw = dict(force_stream=True)   # untuned handles keep k_generic on ragged lines by default
+        kw = {}
         gen = W.random_bytes if case.endswith("random") else W.alphabet_bytes
     cpu = O.CpuOracle(blob)
     for n in (3000, 20000):
@@ -338,7 +338,7 @@ def test_tune_reranks_hot_rows_results_unchanged():
         r, s, e = fn(exe, vec["data"], 4, 0, offsets=vec["offsets"])
         assert np.array_equal(r, vec[verb + "_4_0_res"]) and np.array_equal(e, vec[verb + "_4_0_end"])
         assert np.array_equal(s, vec[verb + "_4_0_start"])
-    # ragged lines: the tuned handle takes k_ragged<..,hot>, an untuned one stays with k_generic
+    # ragged lines take k_ragged<..,hot>, tuned or not
     rng = np.random.default_rng(4)
     lens = rng.integers(0, 300, 5000)
     roff = np.zeros(len(lens) + 1, dtype=np.uint64)
@@ -350,7 +350,7 @@ def test_tune_reranks_hot_rows_results_unchanged():
     for g, e in zip(got, rexp):
         assert np.array_equal(g, e)
     got = one_amd.match_batch(one_amd.Executable(blob), rdata, 4, 0, offsets=roff)
-    assert one_amd.last_kernel() == "k_generic"
+    assert one_amd.last_kernel() == "k_ragged<last,start,end,hot>"
     for g, e in zip(got, rexp):
         assert np.array_equal(g, e)
     # StatefulMatcher: after tuning, whole lines in one chunk reproduce check<styFull>

@@ -5,7 +5,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import numpy as np, torch, one_amd
 from one_amd import workloads as W
 from golden_util import load_dfa
-exe = one_amd.Executable(load_dfa(sys.argv[1] if len(sys.argv) > 1 else "uri"), no_bucketing=(len(sys.argv) > 2))
+exe = one_amd.Executable(load_dfa(sys.argv[1] if len(sys.argv) > 1 else "uri"),
+                         no_bucketing=("nob" in sys.argv[2:]), force_generic=("generic" in sys.argv[2:]))
+print("#", " ".join(sys.argv[1:]) or "uri")
 n = 1 << 20
 data, offsets = W.ragged_lines(n, 32, 256, 4)
 d = torch.from_numpy(data).cuda(); o = torch.from_numpy(offsets.astype(np.int64)).cuda()

@@ -529,23 +529,22 @@ k_tail_pad(const uint8_t *data, const uint64_t *offsets, uint64_t n, uint8_t *pa
   pad[threadIdx.x] = i < total ? data[i] : uint8_t(0);
 }
 
-template <int MODE, bool HOT = false>
-hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
-                         hipStream_t stream) {
-  const uint64_t linesPerTile = uint64_t(kStreamThreads) * kStreamChains;
-  const uint64_t tiles = (b.n + linesPerTile - 1) / linesPerTile;
-  const uint64_t blocks = tiles < uint64_t(cfg.numCUs) ? tiles : uint64_t(cfg.numCUs);
+// The pre-pass shared by k_ragged and the ragged form of k_generic: rb = b plus the tail pad
+// (wantPad) and, for >= 16384 lines unless REDGPU_F_NO_BUCKETING, the length-bucketed
+// permutation with its verdict behind it.  Scratch layout (cached per thread and stream, see
+// raggedScratch): [pad 192 -> 256][perm u32[n]][usePerm u32][pad to 16][hist u32[64 * nb]].
+inline hipError_t prepareRagged(const Batch &b, const LaunchCfg &cfg, hipStream_t stream,
+                                bool wantPad, Batch &rb) {
+  rb = b;
   const bool bucket = b.n >= kBucketMinLines && b.n < (1ull << 32) && !cfg.noBucketing;
-  // scratch (cached per thread and stream, see raggedScratch):
-  //   [pad 192 -> 256][perm u32[n]][usePerm u32][pad to 16][hist u32[64 * nb]]
+  if (!bucket && !wantPad) return hipSuccess;
   const uint32_t nb = bucket ? uint32_t(b.n / 4096 < 256 ? (b.n + 4095) / 4096 : 256) : 0;
   const size_t permBytes = bucket ? (size_t(b.n + 1) * 4 + 15) & ~size_t(15) : 0;
   void *scratch = nullptr;
   hipError_t e = raggedScratch(stream, 256 + permBytes + size_t(kBucketCount) * nb * 4, &scratch);
   if (e != hipSuccess) return e;
-  Batch rb = b;
   uint8_t *pad = static_cast<uint8_t *>(scratch);
-  rb.pad = pad;
+  if (wantPad) rb.pad = pad;
   if (bucket) {
     const uint64_t perBlock = (b.n + nb - 1) / nb;
     uint32_t *perm = reinterpret_cast<uint32_t *>(pad + 256);
@@ -558,6 +557,18 @@ hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
   } else {
     hipLaunchKernelGGL(k_tail_pad, dim3(1), dim3(192), 0, stream, b.data, b.offsets, b.n, pad);
   }
+  return hipGetLastError();
+}
+
+template <int MODE, bool HOT = false>
+hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
+                         hipStream_t stream) {
+  const uint64_t linesPerTile = uint64_t(kStreamThreads) * kStreamChains;
+  const uint64_t tiles = (b.n + linesPerTile - 1) / linesPerTile;
+  const uint64_t blocks = tiles < uint64_t(cfg.numCUs) ? tiles : uint64_t(cfg.numCUs);
+  Batch rb;
+  hipError_t e = prepareRagged(b, cfg, stream, true, rb);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL((k_ragged<MODE, HOT>), dim3(uint32_t(blocks)), dim3(kStreamThreads), 0, stream,
                      d, rb);
   return hipGetLastError();

@@ -567,8 +567,11 @@ k_generic(DevDfa d, Batch b, int style, int lead) {
   c.start2Word[1] = d.start2LeadWord; c.start2Count[1] = d.start2LeadCount;
 
   const uint64_t step = uint64_t(gridDim.x) * kGenericThreads;
-  for (uint64_t line = uint64_t(blockIdx.x) * kGenericThreads + threadIdx.x; line < b.n;
-       line += step) {
+  // ragged lines bucketed by length (k_ragged.h): a wave's 64 lines then end together
+  const bool usePerm = b.perm && b.perm[b.n] != 0;
+  for (uint64_t idx = uint64_t(blockIdx.x) * kGenericThreads + threadIdx.x; idx < b.n;
+       idx += step) {
+    const uint64_t line = usePerm ? b.perm[idx] : idx;
     const uint8_t *p;
     uint64_t n;
     if (b.offsets) {
@@ -1285,8 +1288,15 @@ hipError_t launchGeneric(const DevDfa &d, const Batch &b, int verb, int style, i
     hipError_t e_ = setLds(k_generic<KIND, kThreads, V>, ldsBytes);                          \
     if (e_ != hipSuccess) return e_;                                                         \
     hipLaunchKernelGGL((k_generic<KIND, kThreads, V>), dim3(uint32_t(blocks)), dim3(kThreads), \
-                       ldsBytes, stream, d, b, style, lead);                                 \
+                       ldsBytes, stream, d, pb, style, lead);                                \
   } while (0)
+  // whole-line walks over ragged lines profit from the length bucketing; walks that die in
+  // their first bytes (early-death DFAs under check / match) do not care how long the line is
+  Batch pb = b;
+  if (b.offsets && !(d.earlyDeath && (verb == kCheck || verb == kMatch))) {
+    hipError_t pe = prepareRagged(b, cfg, stream, false, pb);
+    if (pe != hipSuccess) return pe;
+  }
   switch (verb) {
   case kCheck: GEN_LAUNCH(kCheck); break;
   case kScan: GEN_LAUNCH(kScan); break;

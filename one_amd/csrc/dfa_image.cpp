@@ -236,7 +236,19 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
   // The model is also what flags "early death" for every placement (it is skipped for tables so
   // large that the iteration itself would take long).
   std::vector<uint8_t> isHot(stateCnt, 0);
-  const bool wantHot = img.tableKind == REDGPU_TAB_HOT_ROWS;
+  // Hot rows are for tables that do not fit LDS - and, once visits have been OBSERVED
+  // (redgpu_dfa_tune), also for a table of more than 256 states that would fit: when
+  // practically all of the real walk is hot the streaming kernels (one-byte hot index) run it
+  // ~3x faster than k_generic does from an LDS class table.  On the model alone that switch is
+  // not made: a cold excursion per match costs more than the LDS class table saves (343-state
+  // URI DFA, URL in every 8th 64-byte line, untuned: 163 us against 119 us).
+  const uint32_t fitKind = img.tableKind;
+  const bool haveMeasured = measured && measured->size() == stateCnt;
+  const bool wantHot = !forceGlobal && reach.size() > 256 && reach.size() <= 65536 &&
+                       ldsTableMax >= 8u * 256u &&
+                       (fitKind == REDGPU_TAB_HOT_ROWS ||
+                        ((haveMeasured || forceHot) && (fitKind == REDGPU_TAB_LDS_FUSED_U16 ||
+                                                        fitKind == REDGPU_TAB_LDS_CLASS_U16)));
   if (wantHot || uint64_t(reach.size()) * nCls <= (8ull << 20)) {
     std::vector<double> w(nCls, 0.0);
     for (uint32_t b = 0; b < 256; ++b) {
@@ -292,11 +304,14 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
       return total > 0.0 ? c / total : 1.0;
     };
     const uint32_t rows = maxRows;
-    if (coverage(rows) < 0.5 && !forceHot) {
-      // no locality to exploit (e.g. a dense random DFA): the LDS rows would cost occupancy
-      // and catch little - leave the whole table to L2
-      img.tableKind = REDGPU_TAB_GLOBAL_U16;
+    // a table that fits LDS whole gives way only to a hot set that covers practically every
+    // visit; one that does not fit takes hot rows unless there is no locality to exploit (a
+    // dense random DFA), in which case the whole table is left to L2
+    const double need = fitKind == REDGPU_TAB_HOT_ROWS ? 0.5 : 0.999;
+    if (coverage(rows) < need && !forceHot) {
+      img.tableKind = fitKind == REDGPU_TAB_HOT_ROWS ? uint32_t(REDGPU_TAB_GLOBAL_U16) : fitKind;
     } else {
+      img.tableKind = REDGPU_TAB_HOT_ROWS;
       for (uint32_t i = 0; i < rows; ++i) isHot[cand[i]] = 1;
       if (!isHot[rawInit] && klass(rawInit) != 0 && rows) {
         isHot[cand[rows - 1]] = 0;  // the initial state always has a row

@@ -708,10 +708,8 @@ int redgpu_dfa_tune_dev(redgpu_dfa *dfa, const uint8_t *data, const uint64_t *of
   if (!data && (offsets || stride)) return fail(REDGPU_EAPI, "null data buffer");
   DeviceScope scope(dfa->im->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
-  // a table that is in LDS whole has nothing to re-rank
-  if (dfa->im->img.tableKind == REDGPU_TAB_LDS_FUSED_U8 || dfa->im->img.tableKind == REDGPU_TAB_LDS_FUSED_U16 ||
-      dfa->im->img.tableKind == REDGPU_TAB_LDS_CLASS_U16)
-    return REDGPU_OK;
+  // a fused u8 table in LDS (<= 256 states) already takes the streaming kernels
+  if (dfa->im->img.tableKind == REDGPU_TAB_LDS_FUSED_U8) return REDGPU_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const uint32_t nStates = dfa->im->img.nStates;
   uint32_t *dHist = nullptr;

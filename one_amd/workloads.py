@@ -78,6 +78,9 @@ URI_REGEX = (r"(https?|ftps?|file|wss?|sftp|ssh|git|ldaps?)://"
              r"(:[0-9]{1,5})?(/[A-Za-z0-9._~%!$&'()*+,;=:@/-]*)?"
              r"(\?[A-Za-z0-9._~%!$&'()*+,;=:@/?-]*)?(#[A-Za-z0-9._~%-]*)?")
 URI_PLANT = b"https://ab-c.example.com:8080/p/x.y?q=1&r=%20#frag "
+# SURVEY 8a's "userinfo variant": 343 states / 25 classes / 18,124 B through the reference
+URI_USER_REGEX = URI_REGEX.replace("://(", "://([a-z0-9._-]+@)?(", 1)
+URI_USER_PLANT = b"ssh://deploy.bot@build-7.example.org:2222/~/repo.git "
 
 # BASELINE.json configs[4]'s real-regex stand-in (SURVEY 8d "C5" alternative): 20 schemes,
 # userinfo, names / IPv4 / bracketed IPv6, loose start, ignore case -> 3,254 states and 35

@@ -331,6 +331,7 @@ def config_dfas():
     d["aab"] = O.ref_compile([("aab", 1, 0)])
     d["dotstar_err"] = O.ref_compile([(".*error", 1, 0)])
     d["uri_v6"] = O.ref_compile([(W.URI_V6_REGEX, 1, O.F_LOOSE_START | O.F_IGNORE_CASE)])
+    d["uri_user"] = O.ref_compile([(W.URI_USER_REGEX, 1, O.F_LOOSE_START)])
     return d
 
 
@@ -343,6 +344,8 @@ def inputs_for(name: str, rng: np.random.Generator):
     ins += heads[:10] + [h[:-3] for h in heads[10:20]] + [b"x" + h for h in heads[20:24]]
     ins += [W.URI_PLANT, b"see " + W.URI_PLANT, b"http://1.2.3.4", b"ftp://a.bc/",
             b"http://a.b", b"xxhttps://a.io:80/?#", b"HTTP://A.COM"]
+    if name == "uri_user":
+        ins += [W.URI_USER_PLANT, b"at " + W.URI_USER_PLANT + b"x", b"git://u@h.io", b"http://@a.bc"]
     if name == "uri_v6":  # added with that DFA; the older sets keep their recorded inputs
         ins += [W.URI_V6_PLANT, b"go " + W.URI_V6_PLANT + b"tail", b"ssh://[::1]:22/",
                 b"Gopher://U@[1:2:3:4:5:6:7:8]", b"s3://bucket.name.io/k?v#f", b"nfs://[1::]"]

@@ -62,3 +62,16 @@ exe7gg = one_amd.Executable(load_dfa("uri_v6"), force_generic=True, force_global
 timeit(lambda: one_amd.match_batch(exe7gg, d9, 4, 0, stride=L8, n=n8), n8 * L8, "  same (https URL), generic kernel, table in L2 only", it=3)
 exe9 = one_amd.Executable(load_dfa("log100"))
 timeit(lambda: one_amd.match_batch(exe9, d8, 4, 0, stride=L8, n=n8), n8 * L8, "LOG-100 match<Last,false> same text (dies early)", it=3)
+
+# SURVEY's 343-state "userinfo" URI DFA: class table in LDS + k_generic by default; hot rows +
+# streaming kernel when forced / after tuning on representative input
+tt = W.fixed_lines(1 << 20, 64, 2, alphabet=True, plant=W.URI_USER_PLANT, plant_every=8, plant_at=8)
+dd = torch.from_numpy(tt).cuda()
+for kw, label in (({}, "default"), ({"force_hot": True}, "hot rows forced (untuned)")):
+    exe_u2 = one_amd.Executable(load_dfa("uri_user"), **kw)
+    timeit(lambda: one_amd.match_batch(exe_u2, dd, 4, 0, stride=64, n=1 << 20), tt.size,
+           "URI-USER (343 st) 2^20 x 64 B text+URLs, %s [kind %d]" % (label, exe_u2.info["table_kind"]), it=5)
+exe_u3 = one_amd.Executable(load_dfa("uri_user"))
+exe_u3.tune(dd[: 64 << 14], stride=64, n=1 << 14)
+timeit(lambda: one_amd.match_batch(exe_u3, dd, 4, 0, stride=64, n=1 << 20), tt.size,
+       "URI-USER (343 st) same, after tune [kind %d]" % exe_u3.info["table_kind"], it=5)

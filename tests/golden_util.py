@@ -8,7 +8,7 @@ import numpy as np
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 STYLES = ["instant", "first", "tangent", "last", "full"]
 CONFIG_DFAS = ["err", "uri", "log100", "syn256", "num3", "newyork", "aab", "dotstar_err",
-               "uri_v6"]
+               "uri_v6", "uri_user"]
 
 
 def unb64(s):

@@ -108,8 +108,14 @@ def test_table_placement():
     assert i["table_kind"] == 4 and i["n_hot"] == 0
     assert one_amd.Executable(load_dfa("uri"), device="none",
                               force_global=True).info["table_kind"] == 4
+    # a class table that fits LDS whole stays there (only observed visits - redgpu_dfa_tune -
+    # may move such a DFA to hot rows)
     i = one_amd.Executable(load_dfa("log100"), device="none", lds_table_max=400000).info
     assert i["table_kind"] == 3
+    assert one_amd.Executable(load_dfa("uri_user"), device="none").info["table_kind"] == 3
+    from oracle.reda_writer import random_dfa as _rd
+    assert one_amd.Executable(_rd(700, 64, 4), device="none").info["table_kind"] == 3
+    assert one_amd.Executable(_rd(270, 256, 4), device="none").info["table_kind"] == 2
 
 
 def test_host_only_handle_refuses_compute():

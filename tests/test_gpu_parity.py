@@ -211,7 +211,7 @@ def test_hot_row_tables_vs_oracle(rows):
 
 
 @pytest.mark.parametrize("case", ["uri_v6_random", "uri_v6_text", "log100_text", "random_cold",
-                                  "random_cold_dead"])
+                                  "random_cold_dead", "uri_user_text"])
 def test_hot_row_streaming_kernel_vs_oracle(case):
     """k_stream<.., hot>: fixed-stride lines over a DFA too big for LDS.  All-hot walks (random
     bytes over a real regex), walks with cold excursions (planted URLs / log signatures), and a
@@ -224,10 +224,16 @@ def test_hot_row_streaming_kernel_vs_oracle(case):
         exe = one_amd.Executable(blob, force_hot=True, lds_table_max=40 * 256)
         mk = lambda n, L, seed: W.fixed_lines(n, L, seed, alphabet=False)
     else:
-        name = "log100" if case.startswith("log100") else "uri_v6"
+        name = ("log100" if case.startswith("log100") else
+                "uri_user" if case.startswith("uri_user") else "uri_v6")
         blob = load_dfa(name)
-        exe = one_amd.Executable(blob)
-        if case == "uri_v6_random":
+        exe = one_amd.Executable(blob, force_hot=(name == "uri_user"))
+        if case == "uri_user_text":
+            # 343 states: the class table fits LDS; hot rows only when forced or after tuning
+            mk = lambda n, L, seed: W.fixed_lines(n, L, seed, alphabet=True,
+                                                  plant=W.URI_USER_PLANT, plant_every=3,
+                                                  plant_at=L // 2 - 9)
+        elif case == "uri_v6_random":
             mk = lambda n, L, seed: W.fixed_lines(n, L, seed, alphabet=False)
         elif case == "uri_v6_text":
             mk = lambda n, L, seed: W.fixed_lines(n, L, seed, alphabet=True, plant=W.URI_V6_PLANT,
@@ -357,9 +363,22 @@ def test_tune_reranks_hot_rows_results_unchanged():
     state = np.full(n, one_amd.STATE_INITIAL, dtype=np.uint32)
     res = one_amd.advance_batch(exe, held, state, stride=L, n=n)
     assert np.array_equal(res, cpu.batch("check", 5, 0, held, stride=L, n=n, threads=8)[0])
-    # tuning a DFA that lives in LDS whole is a no-op that still validates its arguments
+    # tuning a DFA whose fused table lives in LDS is a no-op that still validates its arguments
     small = one_amd.Executable(load_dfa("uri"))
     assert small.tune(sample, stride=L, n=n)["table_kind"] == 1
+    # a 343-state DFA (class table in LDS, generic kernel) moves to hot rows + streaming kernel
+    # when the observed walk is practically all hot, and stays put when it is not
+    ublob = load_dfa("uri_user")
+    ucpu = O.CpuOracle(ublob)
+    plain = W.fixed_lines(n, L, 33, alphabet=True)
+    mid = one_amd.Executable(ublob)
+    assert mid.info["table_kind"] == 3
+    assert mid.tune(plain, stride=L, n=n)["table_kind"] == 6
+    for data in (plain, held):
+        got = one_amd.match_batch(mid, data, 4, 0, stride=L, n=n)
+        assert "hot" in one_amd.last_kernel()
+        for g, e in zip(got, ucpu.batch("match", 4, 0, data, stride=L, n=n, threads=8)):
+            assert np.array_equal(g, e)
 
 
 def test_split_lines_on_device_then_match():

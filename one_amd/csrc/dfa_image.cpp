@@ -244,11 +244,15 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
   // URI DFA, URL in every 8th 64-byte line, untuned: 163 us against 119 us).
   const uint32_t fitKind = img.tableKind;
   const bool haveMeasured = measured && measured->size() == stateCnt;
+  // a class table of <= 64 KB (<= 127 classes) has its own streaming form (k_stream cls: two
+  // lookups per byte, no cold path, 2.3 TB/s on that same DFA and input) and stays where it is
+  const bool clsStream = nCls <= 127 && uint64_t(reach.size()) * nCls * 2u <= 65536u;
   const bool wantHot = !forceGlobal && reach.size() > 256 && reach.size() <= 65536 &&
                        ldsTableMax >= 8u * 256u &&
                        (fitKind == REDGPU_TAB_HOT_ROWS ||
-                        ((haveMeasured || forceHot) && (fitKind == REDGPU_TAB_LDS_FUSED_U16 ||
-                                                        fitKind == REDGPU_TAB_LDS_CLASS_U16)));
+                        (((haveMeasured && !clsStream) || forceHot) &&
+                         (fitKind == REDGPU_TAB_LDS_FUSED_U16 ||
+                          fitKind == REDGPU_TAB_LDS_CLASS_U16)));
   if (wantHot || uint64_t(reach.size()) * nCls <= (8ull << 20)) {
     std::vector<double> w(nCls, 0.0);
     for (uint32_t b = 0; b < 256; ++b) {
@@ -391,6 +395,7 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
     img.table.assign(size_t(img.nStates) * nCls * w, 0);
     for (size_t k = 0; k < img.next.size(); ++k)
       put(k, img.next[k], w);
+    img.primaryBytes = uint32_t(img.table.size());
     if (img.tableKind == REDGPU_TAB_HOT_ROWS) {
       // [hot index][byte] u8 behind the class table, 16-byte aligned; unused rows and the
       // sink row 255 are all 255; with reachable (absorbing) pure dead ends hot index 0 is
@@ -410,6 +415,22 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
         }
     }
   }
+  }
+  if (img.primaryBytes == 0) img.primaryBytes = uint32_t(img.table.size());
+  if ((img.tableKind == REDGPU_TAB_LDS_CLASS_U16 || img.tableKind == REDGPU_TAB_LDS_FUSED_U16) &&
+      nCls <= 127 && uint64_t(img.nStates) * nCls * 2u <= 65536u) {
+    img.clsRowBytes = nCls * 2u;
+    img.clsOff = uint32_t((img.table.size() + 15u) & ~size_t(15));
+    const uint32_t rows = img.nStates * img.clsRowBytes;
+    img.clsBytes = (256u + rows + 15u) & ~15u;
+    img.table.resize(size_t(img.clsOff) + img.clsBytes, 0);
+    uint8_t *base = &img.table[img.clsOff];
+    for (uint32_t b = 0; b < 256; ++b) base[b] = uint8_t(2u * img.equiv[b]);
+    for (uint32_t i = 0; i < img.nStates; ++i)
+      for (uint32_t c = 0; c < nCls; ++c) {
+        const uint16_t off = uint16_t(img.next[size_t(i) * nCls + c] * img.clsRowBytes);
+        std::memcpy(base + 256 + size_t(i) * img.clsRowBytes + 2 * c, &off, 2);
+      }
   }
   errCode = REDGPU_OK;
   return std::string();

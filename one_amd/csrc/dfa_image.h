@@ -56,7 +56,8 @@ struct DfaImage {
   std::vector<uint32_t> rawOf;    // [nStates] device index -> state id in the blob
   // table chosen for the device
   uint32_t tableKind = 0;         // REDGPU_TAB_*
-  std::vector<uint8_t> table;     // packed bytes of that table
+  std::vector<uint8_t> table;     // packed bytes of that table (+ the appended forms below)
+  uint32_t primaryBytes = 0;      // size of the tableKind table itself, before anything appended
   // REDGPU_TAB_HOT_ROWS: the class table (u16) is followed, at table[hot8Off], by a 64 KB u8
   // table [hot index][byte] -> hot index of the target, 255 = target outside the hot set (row
   // 255 is an absorbing sink).  Hot index of device state s in [hotLo, hotLo + nHot) is
@@ -65,6 +66,11 @@ struct DfaImage {
   //   pure dead | cold non-accepting | hot non-accepting | hot accepting | cold accepting
   // so that the hot set is ONE index range that straddles firstAccept.
   uint32_t hotLo = 0, nHot = 0, hot8Off = 0, hotShift = 0;
+  // LDS_CLASS_U16 / LDS_FUSED_U16 DFAs whose class table is at most 64 KB (and <= 127 classes)
+  // also carry the streaming kernel's form of it at table[clsOff]: 256 bytes eq2 (byte -> 2 x
+  // class), then nStates rows of nClasses u16 = byte offset of the target's row (clsRowBytes =
+  // 2 x nClasses); clsBytes = 256 + rows, rounded up to 16.  0 = not built.
+  uint32_t clsOff = 0, clsRowBytes = 0, clsBytes = 0;
   uint32_t hotCoveragePpm = 0;    // modelled share of visits landing on hot rows
   bool     tuned = false;         // the hot rows were ranked by observed visits (redgpu_dfa_tune)
   bool     earlyDeath = false;    // the model's walk is in a pure dead end within 16 bytes

@@ -121,6 +121,80 @@ __device__ __forceinline__ void streamWalk16(const uint4 (&piece)[2], uint32_t (
 #undef RS_WORD
 }
 
+// ---- class-table form (TABK == kTabCls) ----------------------------------------------------
+// DFAs of more than 256 states whose [state][class] u16 table fits 64 KB (343-state URI DFA:
+// 17 KB).  LDS: [eq2: byte -> 2 x class, 256 B][rows at +256: entry = byte offset of the
+// target's row].  The state register holds a ROW OFFSET, so a step is v_add_u32 (row + 2 x
+// class) and ds_read_u16 ... offset:256; the accept / initial compares work on row offsets
+// unchanged (offsets grow with the state index).  The class lookups do not depend on the
+// state: the four of a word (per chain) are issued ahead by the compiler and only the row
+// lookup sits on the dependent chain.  Two LDS gathers per byte instead of one: half the fused
+// table's rate, four times k_generic's.
+#define RC_ADD(c) "v_add_u32 %[a" #c "], %[s" #c "], %[k" #c "]\n\t"
+#define RC_READ(c) "ds_read_u16 %[t" #c "], %[a" #c "] offset:256\n\t"
+#define RC_I_CHAIN(c) [s##c] "v"(s[c]), [k##c] "v"(cls[c])
+
+template <int MODE, int IDX>
+__device__ __forceinline__ void streamStepCls(uint32_t (&s)[2], const uint32_t (&cls)[2],
+                                              StreamBook (&b)[2], const uint64_t (&wasI)[2],
+                                              uint64_t (&isI)[2], uint32_t T, uint32_t init) {
+  uint32_t a[2], t[2];
+  uint64_t m[2], l[2];
+  if constexpr (MODE == kSmLastStartEnd) {
+    asm volatile(RC_ADD(0) RC_ADD(1) RC_READ(0) RC_READ(1)
+                 RS_CMPA(0) RS_CMPA(1) RS_CMPI(0) RS_CMPI(1)
+                 RS_ACC(0) RS_ACC(1) RS_END(0) RS_END(1)
+                 RS_LEAVE(0) RS_LEAVE(1) RS_START(0) RS_START(1) RS_WAIT
+                 : RS_O_CHAIN(0), RS_O_CHAIN(1), RS_O_ACC(0), RS_O_ACC(1), RS_O_END(0),
+                   RS_O_END(1), RS_O_START(0), RS_O_START(1)
+                 : RC_I_CHAIN(0), RC_I_CHAIN(1), RS_I_START(0), RS_I_START(1), [T] "s"(T),
+                   [init] "s"(init), [idx] "n"(IDX)
+                 : "memory", "scc");
+  } else if constexpr (MODE == kSmLastEnd) {
+    asm volatile(RC_ADD(0) RC_ADD(1) RC_READ(0) RC_READ(1)
+                 RS_CMPA(0) RS_CMPA(1) "s_nop 0\n\t" RS_ACC(0) RS_ACC(1) RS_END(0) RS_END(1) RS_WAIT
+                 : RS_O_CHAIN(0), RS_O_CHAIN(1), RS_O_ACC(0), RS_O_ACC(1), RS_O_END(0), RS_O_END(1)
+                 : RC_I_CHAIN(0), RC_I_CHAIN(1), [T] "s"(T), [idx] "n"(IDX)
+                 : "memory");
+  } else if constexpr (MODE == kSmFullStart) {
+    asm volatile(RC_ADD(0) RC_ADD(1) RC_READ(0) RC_READ(1)
+                 RS_CMPI(0) RS_CMPI(1) "s_nop 0\n\t" RS_LEAVE(0) RS_LEAVE(1) RS_START(0) RS_START(1)
+                 RS_WAIT
+                 : RS_O_CHAIN(0), RS_O_CHAIN(1), RS_O_START(0), RS_O_START(1)
+                 : RC_I_CHAIN(0), RC_I_CHAIN(1), RS_I_START(0), RS_I_START(1), [init] "s"(init),
+                   [idx] "n"(IDX)
+                 : "memory", "scc");
+  } else {
+    asm volatile(RC_ADD(0) RC_ADD(1) RC_READ(0) RC_READ(1) RS_WAIT
+                 : RS_O_CHAIN(0), RS_O_CHAIN(1)
+                 : RC_I_CHAIN(0), RC_I_CHAIN(1)
+                 : "memory");
+  }
+  s[0] = t[0];
+  s[1] = t[1];
+}
+
+template <int MODE, int Q>
+__device__ __forceinline__ void streamWalk16Cls(const uint4 (&piece)[2], uint32_t (&s)[2],
+                                                StreamBook (&b)[2], uint64_t (&mA)[2],
+                                                uint64_t (&mB)[2], uint32_t T, uint32_t init,
+                                                const uint8_t *eq2) {
+  uint32_t cl[4][2];
+#define RC_WORD(K, FIELD)                                                                  \
+  _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                          \
+    cl[k][0] = eq2[(piece[0].FIELD >> (8 * k)) & 0xffu];                                   \
+    cl[k][1] = eq2[(piece[1].FIELD >> (8 * k)) & 0xffu];                                   \
+  }                                                                                        \
+  streamStepCls<MODE, 16 * Q + 4 * K + 0>(s, cl[0], b, mA, mB, T, init);                   \
+  streamStepCls<MODE, 16 * Q + 4 * K + 1>(s, cl[1], b, mB, mA, T, init);                   \
+  streamStepCls<MODE, 16 * Q + 4 * K + 2>(s, cl[2], b, mA, mB, T, init);                   \
+  streamStepCls<MODE, 16 * Q + 4 * K + 3>(s, cl[3], b, mB, mA, T, init);
+  RC_WORD(0, x) RC_WORD(1, y) RC_WORD(2, z) RC_WORD(3, w)
+#undef RC_WORD
+}
+
+constexpr int kTabFused = 0, kTabHot = 1, kTabCls = 2;
+
 // =========================================================================================
 // k_stream<MODE, HALVES>: each lane pulls a whole block of its line - 128 bytes (HALVES = 2,
 // stride % 128 == 0: one full cache line) or 64 bytes (HALVES = 1) - with back-to-back 16-byte
@@ -186,9 +260,12 @@ __device__ __noinline__ SlowBook slowHalf(const DevDfa &d, const uint8_t *tab8, 
   return SlowBook{st, accS, endv, startv};
 }
 
-template <int MODE, int HALVES, int THREADS, bool HOT = false>
+template <int MODE, int HALVES, int THREADS, int TABK = kTabFused>
 __global__ void __launch_bounds__(THREADS)
 k_stream(DevDfa d, Batch io) {
+  constexpr bool HOT = TABK == kTabHot;
+  constexpr bool CLS = TABK == kTabCls;
+  constexpr bool IDXD = HOT || CLS;  // the walk's state values are not device state ids
   constexpr bool EARLY = true;  // first input block requested before the table barrier (-2 %)
   constexpr uint32_t BLK = 64 * HALVES;
   constexpr int CH = kStreamChains;
@@ -201,14 +278,18 @@ k_stream(DevDfa d, Batch io) {
   // HOT: the walk runs in hot-index space (init / firstAccept relative to hotLo; a cold initial
   // state gets an index no lane can hold)
   const uint32_t init =
-      HOT ? (d.init - d.hotLo < d.nHot ? d.init - d.hotLo + d.hotShift : 0x1ffu) : d.init;
-  const uint32_t firstAccept = HOT ? d.firstAccept - d.hotLo + d.hotShift : d.firstAccept;
+      HOT ? (d.init - d.hotLo < d.nHot ? d.init - d.hotLo + d.hotShift : 0x1ffu)
+          : CLS ? d.init * d.clsRowBytes : d.init;
+  const uint32_t firstAccept = HOT ? d.firstAccept - d.hotLo + d.hotShift
+                                   : CLS ? d.firstAccept * d.clsRowBytes : d.firstAccept;
   // HOT: global state id <-> hot index (255 = not hot; index 0 = dead when hotShift)
   auto toHot = [&](uint32_t st) -> uint32_t {
+    if (CLS) return st * d.clsRowBytes;
     if (d.hotShift && st < d.nPureDead) return 0u;
     return st - d.hotLo < d.nHot ? st - d.hotLo + d.hotShift : 255u;
   };
   auto toGlobal = [&](uint32_t idx) -> uint32_t {
+    if (CLS) return idx / d.clsRowBytes;
     return (d.hotShift && idx == 0) ? 0u : d.hotLo + idx - d.hotShift;
   };
   const uint32_t lineLen = uint32_t(io.stride);
@@ -259,22 +340,28 @@ k_stream(DevDfa d, Batch io) {
   // table requests first, the first input block's right behind them (kStreamEarlyIssue), the
   // LDS stores and the barrier after: the table is at the head of the CU's memory queues, the
   // input no longer waits for the barrier before it is even requested
-  const uint4 *tsrc = reinterpret_cast<const uint4 *>(d.table + (HOT ? d.hot8Off : 0u));
-  const uint32_t n16 = HOT ? kStreamTabBytes / 16 : d.tableBytes / 16;
-  uint4 tv[kStreamTabBytes / 16 / THREADS];
+  const uint4 *tsrc =
+      reinterpret_cast<const uint4 *>(d.table + (HOT ? d.hot8Off : CLS ? d.clsOff : 0u));
+  const uint32_t n16 = HOT ? kStreamTabBytes / 16 : CLS ? d.clsBytes / 16 : d.tableBytes / 16;
+  // CLS: 256 bytes of eq2 in front of a table of up to 64 KB - one more 16-byte piece per thread
+  constexpr uint32_t kStagePieces = kStreamTabBytes / 16 / THREADS + (CLS ? 1 : 0);
+  uint4 tv[kStagePieces];
 #pragma unroll
-  for (uint32_t k = 0; k < kStreamTabBytes / 16 / THREADS; ++k) {
+  for (uint32_t k = 0; k < kStagePieces; ++k) {
     const uint32_t i = k * THREADS + threadIdx.x;
     tv[k] = i < n16 ? tsrc[i] : make_uint4(0, 0, 0, 0);
   }
-  const int32_t myRes = HOT ? 0 : threadIdx.x < d.nStates ? d.result[threadIdx.x] : 0;
+  const int32_t myRes = IDXD ? 0 : threadIdx.x < d.nStates ? d.result[threadIdx.x] : 0;
   BlockRegs<HALVES> A[CH], B[CH];
   if (EARLY) issue(A);
   {
     uint4 *dst = reinterpret_cast<uint4 *>(tab);
 #pragma unroll
-    for (uint32_t k = 0; k < kStreamTabBytes / 16 / THREADS; ++k) dst[k * THREADS + threadIdx.x] = tv[k];
-    if (threadIdx.x < 256) ldsRes[threadIdx.x] = myRes;
+    for (uint32_t k = 0; k < kStagePieces; ++k) {
+      const uint32_t i = k * THREADS + threadIdx.x;
+      if (i < (kStreamTabBytes + 1024) / 16) dst[i] = tv[k];
+    }
+    if (!CLS && threadIdx.x < 256) ldsRes[threadIdx.x] = myRes;
   }
   __syncthreads();
 
@@ -293,7 +380,8 @@ k_stream(DevDfa d, Batch io) {
         s[c] = init; accS[c] = 0; endv[c] = 0; startv[c] = 0;
         mA[c] = ~0ull; mB[c] = ~0ull;
         g[c] = kNoState;
-        if (MODE == kSmAdvance && !HOT) s[c] = blk[c].st < d.nStates ? blk[c].st : init;
+        if (MODE == kSmAdvance && !IDXD) s[c] = blk[c].st < d.nStates ? blk[c].st : init;
+        if (MODE == kSmAdvance && CLS) s[c] = toHot(blk[c].st < d.nStates ? blk[c].st : d.init);
         if (MODE == kSmAdvance && HOT) {
           const uint32_t st = blk[c].st < d.nStates ? blk[c].st : d.init;
           s[c] = toHot(st);
@@ -310,22 +398,26 @@ k_stream(DevDfa d, Batch io) {
       uint32_t s0[CH];  // HOT: the half-block's entry state (hot index), for the re-walk
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
-        b[c].acc = HOT ? 0u : accS[c]; b[c].end = 0; b[c].start = 0;
+        b[c].acc = IDXD ? 0u : accS[c]; b[c].end = 0; b[c].start = 0;
         s0[c] = s[c];
       }
       uint4 piece[CH];
 #pragma unroll
       for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[4 * h + 0];
-      streamWalk16<MODE, 0>(piece, s, b, mA, mB, firstAccept, init);
+      if constexpr (CLS) streamWalk16Cls<MODE, 0>(piece, s, b, mA, mB, firstAccept, init, tab);
+      else streamWalk16<MODE, 0>(piece, s, b, mA, mB, firstAccept, init);
 #pragma unroll
       for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[4 * h + 1];
-      streamWalk16<MODE, 1>(piece, s, b, mA, mB, firstAccept, init);
+      if constexpr (CLS) streamWalk16Cls<MODE, 1>(piece, s, b, mA, mB, firstAccept, init, tab);
+      else streamWalk16<MODE, 1>(piece, s, b, mA, mB, firstAccept, init);
 #pragma unroll
       for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[4 * h + 2];
-      streamWalk16<MODE, 2>(piece, s, b, mA, mB, firstAccept, init);
+      if constexpr (CLS) streamWalk16Cls<MODE, 2>(piece, s, b, mA, mB, firstAccept, init, tab);
+      else streamWalk16<MODE, 2>(piece, s, b, mA, mB, firstAccept, init);
 #pragma unroll
       for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[4 * h + 3];
-      streamWalk16<MODE, 3>(piece, s, b, mA, mB, firstAccept, init);
+      if constexpr (CLS) streamWalk16Cls<MODE, 3>(piece, s, b, mA, mB, firstAccept, init, tab);
+      else streamWalk16<MODE, 3>(piece, s, b, mA, mB, firstAccept, init);
       const uint32_t off = r * BLK + h * 64;
       bool redo[CH];
 #pragma unroll
@@ -350,12 +442,12 @@ k_stream(DevDfa d, Batch io) {
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
         if (HOT && redo[c]) continue;
-        if (kAcc && !HOT) {
+        if (kAcc && !IDXD) {
           accS[c] = b[c].acc;
           endv[c] = b[c].end ? off + b[c].end : endv[c];
           if (s[c] >= firstAccept) { accS[c] = s[c]; endv[c] = off + 64; }
         }
-        if (kAcc && HOT) {
+        if (kAcc && IDXD) {
           if (b[c].end) { accS[c] = toGlobal(b[c].acc); endv[c] = off + b[c].end; }
           if (s[c] >= firstAccept) { accS[c] = toGlobal(s[c]); endv[c] = off + 64; }
         }
@@ -374,11 +466,11 @@ k_stream(DevDfa d, Batch io) {
         if (ln < io.n) {
           int32_t rr;
           uint32_t en;
-          const uint32_t sG = !HOT ? s[c] : g[c] != kNoState ? g[c] : toGlobal(s[c]);
+          const uint32_t sG = !IDXD ? s[c] : g[c] != kNoState ? g[c] : toGlobal(s[c]);
           if (kAcc) {
-            rr = endv[c] ? (HOT ? d.result[accS[c]] : ldsRes[accS[c]]) : 0;
+            rr = endv[c] ? (IDXD ? d.result[accS[c]] : ldsRes[accS[c]]) : 0;
             en = endv[c];
-          } else if (HOT) {
+          } else if (IDXD) {
             rr = sG >= d.firstAccept ? d.result[sG] : 0;
             en = lineLen;
           } else {
@@ -404,8 +496,8 @@ k_stream(DevDfa d, Batch io) {
   }
 }
 
-// the HOT form of the same launch (512 threads only)
-template <int MODE>
+// the HOT / CLS forms of the same launch (512 threads only)
+template <int MODE, int TABK = kTabHot>
 hipError_t launchStreamHot(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
                            hipStream_t stream) {
   constexpr int THREADS = kStreamThreads;
@@ -413,10 +505,10 @@ hipError_t launchStreamHot(const DevDfa &d, const Batch &b, const LaunchCfg &cfg
   const uint64_t tiles = (b.n + linesPerTile - 1) / linesPerTile;
   const uint64_t blocks = tiles < uint64_t(cfg.numCUs) ? tiles : uint64_t(cfg.numCUs);
   if (b.stride % 128 == 0)
-    hipLaunchKernelGGL((k_stream<MODE, 2, THREADS, true>), dim3(uint32_t(blocks)), dim3(THREADS),
+    hipLaunchKernelGGL((k_stream<MODE, 2, THREADS, TABK>), dim3(uint32_t(blocks)), dim3(THREADS),
                        0, stream, d, b);
   else
-    hipLaunchKernelGGL((k_stream<MODE, 1, THREADS, true>), dim3(uint32_t(blocks)), dim3(THREADS),
+    hipLaunchKernelGGL((k_stream<MODE, 1, THREADS, TABK>), dim3(uint32_t(blocks)), dim3(THREADS),
                        0, stream, d, b);
   return hipGetLastError();
 }

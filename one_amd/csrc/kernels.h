@@ -27,6 +27,7 @@ struct DevDfa {
   // REDGPU_TAB_HOT_ROWS (dfa_image.h), else 0: hot states [hotLo, hotLo + nHot), the 64 KB
   // [hot index][byte] u8 table at table + hot8Off, hot index = s - hotLo + hotShift
   uint32_t hotLo, nHot, hot8Off, hotShift;
+  uint32_t clsOff, clsRowBytes, clsBytes;  // streaming form of a <= 64 KB class table, or 0
   uint32_t earlyDeath;           // the visit model sees walks die within 16 bytes
   uint32_t tuned;                // hot rows ranked by observed visits
   // start bytes for scan / search (dfa_image.h): packed members, count (0xff = no filter)

@@ -1431,6 +1431,11 @@ static bool hotStreamEligible(const DevDfa &d) {
          d.deadAbsorbing;
 }
 
+// DFAs of more than 256 states with a class table of at most 64 KB: k_stream's class-table form
+static bool clsStreamEligible(const DevDfa &d) {
+  return d.clsOff != 0 && d.clsBytes <= kStreamTabBytes + 1024 && d.deadAbsorbing;
+}
+
 bool fastPathEligible(const DevDfa &d) {
   return d.tableKind == REDGPU_TAB_LDS_FUSED_U8 && d.deadAbsorbing &&
          size_t(d.tableBytes) + size_t(d.nStates) * 4 <= 150 * 1024;
@@ -1582,6 +1587,16 @@ hipError_t launchAdvance(const DevDfa &d, const Batch &b, uint32_t *state, const
     sb.end = nullptr;
     return launchStreamT<kSmAdvance>(d, sb, cfg, stream);
   }
+  if (!cfg.forceGeneric && clsStreamEligible(d) && !b.offsets && b.stride >= 64 &&
+      b.stride % 64 == 0 && b.stride < (1ull << 31) &&
+      (reinterpret_cast<uintptr_t>(b.data) % 16) == 0) {
+    *kernelName = "k_stream<advance,cls>";
+    Batch sb = b;
+    sb.state = state;
+    sb.start = nullptr;
+    sb.end = nullptr;
+    return launchStreamHot<kSmAdvance, kTabCls>(d, sb, cfg, stream);
+  }
   if (!cfg.forceGeneric && hotStreamEligible(d) && !b.offsets && b.stride >= 64 &&
       b.stride % 64 == 0 && b.stride < (1ull << 31) &&
       (reinterpret_cast<uintptr_t>(b.data) % 16) == 0) {
@@ -1657,6 +1672,32 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
     } else {
       if (sb.start) { *kernelName = "k_stream<full,start,hot>"; e = launchStreamHot<kSmFullStart>(d, sb, cfg, stream); }
       else { *kernelName = "k_stream<full,hot>"; e = launchStreamHot<kSmFull>(d, sb, cfg, stream); }
+    }
+    if (e != hipSuccess) return e;
+    if (lead) {
+      hipLaunchKernelGGL(k_leader_filter, dim3(uint32_t(cfg.numCUs) * 8), dim3(256), 0, stream,
+                         d, b);
+      return hipGetLastError();
+    }
+    return hipSuccess;
+  }
+  // ... and for mid-size DFAs whose class table fits 64 KB of LDS (two lookups per byte)
+  const bool clsStreamOk = !cfg.forceGeneric && !dying && clsStreamEligible(d) && !b.offsets &&
+                           (verb == kCheck || verb == kMatch) &&
+                           (style == kStyLast || style == kStyFull) && b.stride >= 64 &&
+                           b.stride % 64 == 0 && b.stride < (1ull << 31) &&
+                           (reinterpret_cast<uintptr_t>(b.data) % 16) == 0 &&
+                           !(lead && verb == kCheck);
+  if (clsStreamOk) {
+    hipError_t e;
+    Batch sb = b;
+    if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
+    if (style == kStyLast) {
+      if (sb.start) { *kernelName = "k_stream<last,start,end,cls>"; e = launchStreamHot<kSmLastStartEnd, kTabCls>(d, sb, cfg, stream); }
+      else { *kernelName = "k_stream<last,end,cls>"; e = launchStreamHot<kSmLastEnd, kTabCls>(d, sb, cfg, stream); }
+    } else {
+      if (sb.start) { *kernelName = "k_stream<full,start,cls>"; e = launchStreamHot<kSmFullStart, kTabCls>(d, sb, cfg, stream); }
+      else { *kernelName = "k_stream<full,cls>"; e = launchStreamHot<kSmFull, kTabCls>(d, sb, cfg, stream); }
     }
     if (e != hipSuccess) return e;
     if (lead) {

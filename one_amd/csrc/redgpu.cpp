@@ -236,7 +236,7 @@ int uploadImage(SharedImage *im) {
   d.result = static_cast<const int32_t *>(im->dResult);
   d.equivLeader = static_cast<const uint8_t *>(im->dEquivLeader);
   d.tableKind = img.tableKind;
-  d.tableBytes = uint32_t(tabBytes);
+  d.tableBytes = (img.primaryBytes + 15u) & ~15u;  // the tableKind table only (LDS staging size)
   d.nStates = img.nStates;
   d.nClasses = img.nClasses;
   d.init = img.init;
@@ -250,6 +250,9 @@ int uploadImage(SharedImage *im) {
   d.hot8Off = img.hot8Off;
   d.hotShift = img.hotShift;
   d.earlyDeath = img.earlyDeath ? 1 : 0;
+  d.clsOff = img.clsOff;
+  d.clsRowBytes = img.clsRowBytes;
+  d.clsBytes = img.clsBytes;
   d.tuned = img.tuned ? 1 : 0;
   d.startLeadWord = img.startLeadWord;
   d.startLeadCount = img.startLeadCount;
@@ -394,7 +397,7 @@ int redgpu_dfa_info(const redgpu_dfa *h, redgpu_info *out) {
   out->n_pure_dead = img.nPureDead;
   out->first_accept = img.firstAccept;
   out->table_kind = img.tableKind;
-  out->table_bytes = img.table.size();
+  out->table_bytes = img.primaryBytes;
   out->max_result = img.maxResult;
   out->device = h->im->device;
   out->checksum = img.checksum;

@@ -320,6 +320,54 @@ def test_hot_row_ragged_kernel_vs_oracle(case):
                                       cpu.batch("check", sty, 0, data, offsets=offsets, threads=8)[0])
 
 
+@pytest.mark.parametrize("case", ["uri_user", "rnd700x30", "rnd257x100_dead", "rnd1300x25"])
+def test_class_table_streaming_kernel_vs_oracle(case):
+    """k_stream<.., cls>: fixed-stride lines over a DFA of more than 256 states whose class table
+    (<= 64 KB) sits in LDS in row-offset form - two lookups per byte, no cold path.  Every mode,
+    64- and 128-byte blocks, ragged last tile, the leader filter, StatefulMatcher chunks."""
+    if case == "uri_user":
+        blob = load_dfa("uri_user")
+        mk = lambda n, L, seed: W.fixed_lines(n, L, seed, alphabet=True, plant=W.URI_USER_PLANT,
+                                              plant_every=3, plant_at=L // 2 - 20)
+    else:
+        n_st, n_cls = {"rnd700x30": (700, 30), "rnd257x100_dead": (258, 100),
+                       "rnd1300x25": (1300, 25)}[case]
+        blob = random_dfa(n_st, n_cls, 91, dead_frac=0.01 if case.endswith("dead") else 0.0,
+                          accept_frac=0.15)
+        mk = lambda n, L, seed: W.fixed_lines(n, L, seed, alphabet=False)
+    exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
+    assert exe.info["table_kind"] in (2, 3), exe.info
+    for n, L in ((3001, 64), (1500, 128), (700, 192), (130, 4096)):
+        data = mk(n, L, 200 + L)
+        for sty in (4, 5):
+            er, es, ee = cpu.batch("match", sty, 0, data, stride=L, n=n, threads=8)
+            r, s, e = one_amd.match_batch(exe, data, sty, 0, stride=L, n=n)
+            assert one_amd.last_kernel().endswith("cls>"), one_amd.last_kernel()
+            assert np.array_equal(r, er), (case, n, L, sty)
+            assert np.array_equal(s, es) and np.array_equal(e, ee), (case, n, L, sty)
+            r, _, e = one_amd.match_batch(exe, data, sty, 1, stride=L, n=n, want_start=False)
+            er1, _, ee1 = cpu.batch("match", sty, 1, data, stride=L, n=n, threads=8)
+            assert np.array_equal(r, er1) and np.array_equal(e, ee1)
+            assert np.array_equal(one_amd.check_batch(exe, data, sty, 0, stride=L, n=n),
+                                  cpu.batch("check", sty, 0, data, stride=L, n=n, threads=8)[0])
+        state = np.full(n, one_amd.STATE_INITIAL, dtype=np.uint32)
+        if L % 128 == 0:
+            a = data.reshape(n, L)
+            for half in (a[:, :L // 2], a[:, L // 2:]):
+                res = one_amd.advance_batch(exe, np.ascontiguousarray(half).reshape(-1), state,
+                                            stride=L // 2, n=n)
+        else:
+            res = one_amd.advance_batch(exe, data, state, stride=L, n=n)
+        assert one_amd.last_kernel() == "k_stream<advance,cls>"
+        ostate = np.full(n, O.STATE_INITIAL, dtype=np.uint32)
+        assert np.array_equal(res, cpu.advance_batch(data, ostate, stride=L, n=n))
+        # the generic kernel must leave the same state tokens behind
+        gen = one_amd.Executable(blob, force_generic=True)
+        gstate = np.full(n, one_amd.STATE_INITIAL, dtype=np.uint32)
+        one_amd.advance_batch(gen, data, gstate, stride=L, n=n)
+        assert np.array_equal(gstate, state)
+
+
 def test_tune_reranks_hot_rows_results_unchanged():
     """redgpu_dfa_tune: visits counted on a sample of URL-bearing text re-rank the hot rows;
     outputs stay bit-exact, the share of the walk served from LDS goes up (measured on held-out
@@ -366,18 +414,25 @@ def test_tune_reranks_hot_rows_results_unchanged():
     # tuning a DFA whose fused table lives in LDS is a no-op that still validates its arguments
     small = one_amd.Executable(load_dfa("uri"))
     assert small.tune(sample, stride=L, n=n)["table_kind"] == 1
-    # a 343-state DFA (class table in LDS, generic kernel) moves to hot rows + streaming kernel
-    # when the observed walk is practically all hot, and stays put when it is not
-    ublob = load_dfa("uri_user")
-    ucpu = O.CpuOracle(ublob)
-    plain = W.fixed_lines(n, L, 33, alphabet=True)
-    mid = one_amd.Executable(ublob)
-    assert mid.info["table_kind"] == 3
-    assert mid.tune(plain, stride=L, n=n)["table_kind"] == 6
-    for data in (plain, held):
-        got = one_amd.match_batch(mid, data, 4, 0, stride=L, n=n)
+    # a DFA of more than 256 states whose class table fits LDS but not the 64 KB streaming form
+    # (1500 states x 40 classes = 120 KB: generic kernel) moves to hot rows + streaming kernel
+    # when the observed walk is practically all hot; a 343-state one (17 KB class table: its
+    # own streaming form, k_stream cls) stays where it is
+    mid = one_amd.Executable(load_dfa("uri_user"))
+    assert mid.info["table_kind"] == 3 and mid.tune(held, stride=L, n=n)["table_kind"] == 3
+    one_amd.match_batch(mid, held, 4, 0, stride=L, n=n)
+    assert one_amd.last_kernel() == "k_stream<last,start,end,cls>"
+    bblob = random_dfa(1500, 40, 5, accept_frac=0.1)
+    big = one_amd.Executable(bblob)
+    assert big.info["table_kind"] == 3
+    zeros = np.zeros(n * L, dtype=np.uint8)           # a walk that soon cycles through few states
+    after_big = big.tune(zeros, stride=L, n=n)
+    assert after_big["table_kind"] == 6, after_big
+    bcpu = O.CpuOracle(bblob)
+    for data in (zeros, held):
+        got = one_amd.match_batch(big, data, 4, 0, stride=L, n=n)
         assert "hot" in one_amd.last_kernel()
-        for g, e in zip(got, ucpu.batch("match", 4, 0, data, stride=L, n=n, threads=8)):
+        for g, e in zip(got, bcpu.batch("match", 4, 0, data, stride=L, n=n, threads=8)):
             assert np.array_equal(g, e)
 
 

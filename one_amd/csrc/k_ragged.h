@@ -108,6 +108,74 @@ __device__ __forceinline__ void raggedWalk16(const uint4 (&piece)[2], uint32_t (
 #undef RG_WORD
 }
 
+// class-table form of the step (k_stream.h, TABK == kTabCls): row + 2 x class, ds_read_u16
+#define RGC_I_CHAIN(c) [s##c] "v"(s[c]), [k##c] "v"(cls[c]), [rem##c] "v"(rem[c])
+
+template <int MODE, int IDX>
+__device__ __forceinline__ void raggedStepCls(uint32_t (&s)[2], const uint32_t (&cls)[2],
+                                              const uint32_t (&rem)[2], StreamBook (&b)[2],
+                                              const uint64_t (&wasI)[2], uint64_t (&isI)[2],
+                                              const uint64_t (&validPrev)[2],
+                                              uint64_t (&validNow)[2], uint32_t T, uint32_t init) {
+  uint32_t a[2], t[2];
+  uint64_t m[2], mr[2], l[2];
+  if constexpr (MODE == kSmLastStartEnd) {
+    asm volatile(RC_ADD(0) RC_ADD(1) RC_READ(0) RC_READ(1) RG_VALID(0) RG_VALID(1)
+                 RG_CMPA(0) RG_CMPA(1) RG_CMPI(0) RG_CMPI(1) RG_ACC(0) RG_ACC(1)
+                 RG_MEND(0) RG_MEND(1) RG_END(0) RG_END(1)
+                 RG_LEAVE(0) RG_LEAVE(1) RG_START(0) RG_START(1) RG_WAIT RG_HOLD(0) RG_HOLD(1)
+                 : RG_O_CHAIN(0), RG_O_CHAIN(1), RG_O_ACC(0), RG_O_ACC(1), RG_O_START(0),
+                   RG_O_START(1)
+                 : RGC_I_CHAIN(0), RGC_I_CHAIN(1), RG_I_ACC(0), RG_I_ACC(1), RG_I_START(0),
+                   RG_I_START(1), [T] "s"(T), [init] "s"(init), [idx] "n"(IDX)
+                 : "memory", "scc");
+  } else if constexpr (MODE == kSmLastEnd) {
+    asm volatile(RC_ADD(0) RC_ADD(1) RC_READ(0) RC_READ(1) RG_VALID(0) RG_VALID(1)
+                 RG_CMPA(0) RG_CMPA(1) "s_nop 0\n\t" RG_ACC(0) RG_ACC(1)
+                 RG_MEND(0) RG_MEND(1) RG_END(0) RG_END(1) RG_WAIT RG_HOLD(0) RG_HOLD(1)
+                 : RG_O_CHAIN(0), RG_O_CHAIN(1), RG_O_ACC(0), RG_O_ACC(1)
+                 : RGC_I_CHAIN(0), RGC_I_CHAIN(1), RG_I_ACC(0), RG_I_ACC(1), [T] "s"(T),
+                   [idx] "n"(IDX)
+                 : "memory", "scc");
+  } else if constexpr (MODE == kSmFullStart) {
+    asm volatile(RC_ADD(0) RC_ADD(1) RC_READ(0) RC_READ(1) RG_VALID(0) RG_VALID(1)
+                 RG_CMPI(0) RG_CMPI(1) "s_nop 0\n\t" RG_LEAVE(0) RG_LEAVE(1)
+                 RG_START(0) RG_START(1) RG_WAIT RG_HOLD(0) RG_HOLD(1)
+                 : RG_O_CHAIN(0), RG_O_CHAIN(1), RG_O_START(0), RG_O_START(1)
+                 : RGC_I_CHAIN(0), RGC_I_CHAIN(1), RG_I_START(0), RG_I_START(1),
+                   [init] "s"(init), [idx] "n"(IDX)
+                 : "memory", "scc");
+  } else {
+    asm volatile(RC_ADD(0) RC_ADD(1) RC_READ(0) RC_READ(1) RG_VALID(0) RG_VALID(1)
+                 RG_WAIT "s_nop 0\n\t" RG_HOLD(0) RG_HOLD(1)
+                 : RG_O_CHAIN(0), RG_O_CHAIN(1)
+                 : RGC_I_CHAIN(0), RGC_I_CHAIN(1), [idx] "n"(IDX)
+                 : "memory");
+  }
+  s[0] = t[0];
+  s[1] = t[1];
+}
+
+template <int MODE, int Q>
+__device__ __forceinline__ void raggedWalk16Cls(const uint4 (&piece)[2], uint32_t (&s)[2],
+                                                const uint32_t (&rem)[2], StreamBook (&b)[2],
+                                                uint64_t (&mA)[2], uint64_t (&mB)[2],
+                                                uint64_t (&vA)[2], uint64_t (&vB)[2], uint32_t T,
+                                                uint32_t init, const uint8_t *eq2) {
+  uint32_t cl[4][2];
+#define RGC_WORD(K, FIELD)                                                                   \
+  _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                            \
+    cl[k][0] = eq2[(piece[0].FIELD >> (8 * k)) & 0xffu];                                     \
+    cl[k][1] = eq2[(piece[1].FIELD >> (8 * k)) & 0xffu];                                     \
+  }                                                                                          \
+  raggedStepCls<MODE, 16 * Q + 4 * K + 0>(s, cl[0], rem, b, mA, mB, vA, vB, T, init);        \
+  raggedStepCls<MODE, 16 * Q + 4 * K + 1>(s, cl[1], rem, b, mB, mA, vB, vA, T, init);        \
+  raggedStepCls<MODE, 16 * Q + 4 * K + 2>(s, cl[2], rem, b, mA, mB, vA, vB, T, init);        \
+  raggedStepCls<MODE, 16 * Q + 4 * K + 3>(s, cl[3], rem, b, mB, mA, vB, vA, T, init);
+  RGC_WORD(0, x) RGC_WORD(1, y) RGC_WORD(2, z) RGC_WORD(3, w)
+#undef RGC_WORD
+}
+
 __device__ __forceinline__ uint32_t waveMaxU32(uint32_t v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
@@ -156,9 +224,12 @@ __device__ __noinline__ SlowBook slowRagged(const DevDfa &d, const uint8_t *tab8
   return SlowBook{st, accS, endv, startv};
 }
 
-template <int MODE, bool HOT = false>
+template <int MODE, int TABK = kTabFused>
 __global__ void __launch_bounds__(kStreamThreads)
 k_ragged(DevDfa d, Batch io) {
+  constexpr bool HOT = TABK == kTabHot;
+  constexpr bool CLS = TABK == kTabCls;
+  constexpr bool IDXD = HOT || CLS;  // the walk's state values are not device state ids
   constexpr int CH = kStreamChains;
   constexpr int THREADS = kStreamThreads;
   constexpr bool kAcc = MODE == kSmLastStartEnd || MODE == kSmLastEnd;
@@ -169,32 +240,41 @@ k_ragged(DevDfa d, Batch io) {
 
   // HOT: the walk runs in hot-index space (k_stream.h)
   const uint32_t init =
-      HOT ? (d.init - d.hotLo < d.nHot ? d.init - d.hotLo + d.hotShift : 0x1ffu) : d.init;
-  const uint32_t firstAccept = HOT ? d.firstAccept - d.hotLo + d.hotShift : d.firstAccept;
+      HOT ? (d.init - d.hotLo < d.nHot ? d.init - d.hotLo + d.hotShift : 0x1ffu)
+          : CLS ? d.init * d.clsRowBytes : d.init;
+  const uint32_t firstAccept = HOT ? d.firstAccept - d.hotLo + d.hotShift
+                                   : CLS ? d.firstAccept * d.clsRowBytes : d.firstAccept;
   auto toHot = [&](uint32_t st) -> uint32_t {
+    if (CLS) return st * d.clsRowBytes;
     if (d.hotShift && st < d.nPureDead) return 0u;
     return st - d.hotLo < d.nHot ? st - d.hotLo + d.hotShift : 255u;
   };
   auto toGlobal = [&](uint32_t idx) -> uint32_t {
+    if (CLS) return idx / d.clsRowBytes;
     return (d.hotShift && idx == 0) ? 0u : d.hotLo + idx - d.hotShift;
   };
   const uint64_t linesPerTile = uint64_t(THREADS) * CH;
   const uint64_t nTiles = (io.n + linesPerTile - 1) / linesPerTile;
   if (blockIdx.x >= nTiles) return;
   {
-    const uint4 *src = reinterpret_cast<const uint4 *>(d.table + (HOT ? d.hot8Off : 0u));
-    const uint32_t n16 = HOT ? kStreamTabBytes / 16 : d.tableBytes / 16;
-    uint4 v[kStreamTabBytes / 16 / THREADS];
+    const uint4 *src =
+        reinterpret_cast<const uint4 *>(d.table + (HOT ? d.hot8Off : CLS ? d.clsOff : 0u));
+    const uint32_t n16 = HOT ? kStreamTabBytes / 16 : CLS ? d.clsBytes / 16 : d.tableBytes / 16;
+    constexpr uint32_t kStagePieces = kStreamTabBytes / 16 / THREADS + (CLS ? 1 : 0);
+    uint4 v[kStagePieces];
 #pragma unroll
-    for (uint32_t k = 0; k < kStreamTabBytes / 16 / THREADS; ++k) {
+    for (uint32_t k = 0; k < kStagePieces; ++k) {
       const uint32_t i = k * THREADS + threadIdx.x;
       v[k] = i < n16 ? src[i] : make_uint4(0, 0, 0, 0);
     }
-    const int32_t myRes = HOT ? 0 : threadIdx.x < d.nStates ? d.result[threadIdx.x] : 0;
+    const int32_t myRes = IDXD ? 0 : threadIdx.x < d.nStates ? d.result[threadIdx.x] : 0;
     uint4 *dst = reinterpret_cast<uint4 *>(tab);
 #pragma unroll
-    for (uint32_t k = 0; k < kStreamTabBytes / 16 / THREADS; ++k) dst[k * THREADS + threadIdx.x] = v[k];
-    if (threadIdx.x < 256) ldsRes[threadIdx.x] = myRes;
+    for (uint32_t k = 0; k < kStagePieces; ++k) {
+      const uint32_t i = k * THREADS + threadIdx.x;
+      if (i < (kStreamTabBytes + 1024) / 16) dst[i] = v[k];
+    }
+    if (!CLS && threadIdx.x < 256) ldsRes[threadIdx.x] = myRes;
   }
   __syncthreads();
 
@@ -202,7 +282,7 @@ k_ragged(DevDfa d, Batch io) {
   const uint64_t padStart = total >= 128 ? total - 128 : 0;  // pad[] = data[padStart, total) + 0s
   // the bucketing pass's verdict sits right behind the permutation
   const bool usePerm = io.perm && io.perm[io.n] != 0;
-  const int32_t initResult = HOT ? (d.init >= d.firstAccept ? d.result[d.init] : 0)
+  const int32_t initResult = IDXD ? (d.init >= d.firstAccept ? d.result[d.init] : 0)
                                  : (init >= firstAccept ? ldsRes[init] : 0);
 
   for (uint64_t tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
@@ -264,22 +344,26 @@ k_ragged(DevDfa d, Batch io) {
       for (int c = 0; c < CH; ++c) {
         const uint32_t done = r * 64;
         rem[c] = len[c] > done ? (len[c] - done > 64 ? 64 : len[c] - done) : 0;
-        b[c].acc = HOT ? 0u : accS[c]; b[c].end = 0; b[c].start = 0;
+        b[c].acc = IDXD ? 0u : accS[c]; b[c].end = 0; b[c].start = 0;
         s0[c] = s[c];
       }
       uint4 piece[CH];
 #pragma unroll
       for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[0];
-      raggedWalk16<MODE, 0>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
+      if constexpr (CLS) raggedWalk16Cls<MODE, 0>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init, tab);
+      else raggedWalk16<MODE, 0>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
 #pragma unroll
       for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[1];
-      raggedWalk16<MODE, 1>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
+      if constexpr (CLS) raggedWalk16Cls<MODE, 1>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init, tab);
+      else raggedWalk16<MODE, 1>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
 #pragma unroll
       for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[2];
-      raggedWalk16<MODE, 2>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
+      if constexpr (CLS) raggedWalk16Cls<MODE, 2>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init, tab);
+      else raggedWalk16<MODE, 2>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
 #pragma unroll
       for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[3];
-      raggedWalk16<MODE, 3>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
+      if constexpr (CLS) raggedWalk16Cls<MODE, 3>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init, tab);
+      else raggedWalk16<MODE, 3>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
       // fold (as k_stream); the state after the block's 64th byte counts only if that byte
       // was part of the line (rem == 64) - vA holds "step 63 was valid" for exactly that
       const uint32_t off = r * 64;
@@ -305,14 +389,14 @@ k_ragged(DevDfa d, Batch io) {
       for (int c = 0; c < CH; ++c) {
         if (HOT && redo[c]) continue;
         const bool full = rem[c] == 64;
-        if (kAcc && !HOT) {
+        if (kAcc && !IDXD) {
           accS[c] = b[c].acc;
           endv[c] = b[c].end ? off + b[c].end : endv[c];
           if (full && s[c] >= firstAccept) { accS[c] = s[c]; endv[c] = off + 64; }
         }
-        if (kAcc && HOT) {
+        if (kAcc && IDXD) {
           if (b[c].end) { accS[c] = toGlobal(b[c].acc); endv[c] = off + b[c].end; }
-          if (full && s[c] >= firstAccept && s[c] != 255u) {
+          if (full && s[c] >= firstAccept && (CLS || s[c] != 255u)) {
             accS[c] = toGlobal(s[c]);
             endv[c] = off + 64;
           }
@@ -343,9 +427,9 @@ k_ragged(DevDfa d, Batch io) {
         en = 0;
         startv[c] = 0;
       } else if (kAcc) {
-        rr = endv[c] ? (HOT ? d.result[accS[c]] : ldsRes[accS[c]]) : 0;
+        rr = endv[c] ? (IDXD ? d.result[accS[c]] : ldsRes[accS[c]]) : 0;
         en = endv[c];
-      } else if (HOT) {
+      } else if (IDXD) {
         const uint32_t sG = g[c] != kNoState ? g[c] : toGlobal(s[c]);
         rr = sG >= d.firstAccept ? d.result[sG] : 0;
         en = len[c];
@@ -560,7 +644,7 @@ inline hipError_t prepareRagged(const Batch &b, const LaunchCfg &cfg, hipStream_
   return hipGetLastError();
 }
 
-template <int MODE, bool HOT = false>
+template <int MODE, int TABK = kTabFused>
 hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
                          hipStream_t stream) {
   const uint64_t linesPerTile = uint64_t(kStreamThreads) * kStreamChains;
@@ -569,7 +653,7 @@ hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
   Batch rb;
   hipError_t e = prepareRagged(b, cfg, stream, true, rb);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_ragged<MODE, HOT>), dim3(uint32_t(blocks)), dim3(kStreamThreads), 0, stream,
+  hipLaunchKernelGGL((k_ragged<MODE, TABK>), dim3(uint32_t(blocks)), dim3(kStreamThreads), 0, stream,
                      d, rb);
   return hipGetLastError();
 }

@@ -1762,13 +1762,30 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
     Batch sb = b;
     if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
     if (style == kStyLast) {
-      if (sb.start) { *kernelName = "k_ragged<last,start,end,hot>"; return launchRaggedT<kSmLastStartEnd, true>(d, sb, cfg, stream); }
+      if (sb.start) { *kernelName = "k_ragged<last,start,end,hot>"; return launchRaggedT<kSmLastStartEnd, kTabHot>(d, sb, cfg, stream); }
       *kernelName = "k_ragged<last,end,hot>";
-      return launchRaggedT<kSmLastEnd, true>(d, sb, cfg, stream);
+      return launchRaggedT<kSmLastEnd, kTabHot>(d, sb, cfg, stream);
     }
-    if (sb.start) { *kernelName = "k_ragged<full,start,hot>"; return launchRaggedT<kSmFullStart, true>(d, sb, cfg, stream); }
+    if (sb.start) { *kernelName = "k_ragged<full,start,hot>"; return launchRaggedT<kSmFullStart, kTabHot>(d, sb, cfg, stream); }
     *kernelName = "k_ragged<full,hot>";
-    return launchRaggedT<kSmFull, true>(d, sb, cfg, stream);
+    return launchRaggedT<kSmFull, kTabHot>(d, sb, cfg, stream);
+  }
+
+  // ... and for mid-size DFAs with a class table of at most 64 KB
+  const bool clsRaggedOk = !cfg.forceGeneric && !dying && clsStreamEligible(d) && b.offsets &&
+                           (verb == kCheck || verb == kMatch) &&
+                           (style == kStyLast || style == kStyFull) && !lead;
+  if (clsRaggedOk) {
+    Batch sb = b;
+    if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
+    if (style == kStyLast) {
+      if (sb.start) { *kernelName = "k_ragged<last,start,end,cls>"; return launchRaggedT<kSmLastStartEnd, kTabCls>(d, sb, cfg, stream); }
+      *kernelName = "k_ragged<last,end,cls>";
+      return launchRaggedT<kSmLastEnd, kTabCls>(d, sb, cfg, stream);
+    }
+    if (sb.start) { *kernelName = "k_ragged<full,start,cls>"; return launchRaggedT<kSmFullStart, kTabCls>(d, sb, cfg, stream); }
+    *kernelName = "k_ragged<full,cls>";
+    return launchRaggedT<kSmFull, kTabCls>(d, sb, cfg, stream);
   }
 
   *kernelName = "k_generic";

@@ -25,7 +25,7 @@ for dd, oo, label in ((d, o, "uniform"), (d2, o2, "geometric")):
     ms = a.elapsed_time(b) / 10
     print(label, "%.1f us  %.1f GB/s" % (ms * 1e3, dd.numel() / ms / 1e6), one_amd.last_kernel(), flush=True)
 # big real-regex DFA (hot rows) on the same geometric text lines, untuned and tuned
-if len(sys.argv) > 1 and sys.argv[1] == "uri_v6":
+if len(sys.argv) > 1 and sys.argv[1] in ("uri_v6", "uri_user"):
     t = W.alphabet_bytes(int(off2[-1]), 19).copy()
     for k in range(0, t.size - 100, 1200):
         t[k:k + len(W.URI_PLANT)] = np.frombuffer(W.URI_PLANT, dtype=np.uint8)

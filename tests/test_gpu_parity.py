@@ -368,6 +368,44 @@ def test_class_table_streaming_kernel_vs_oracle(case):
         assert np.array_equal(gstate, state)
 
 
+@pytest.mark.parametrize("case", ["uri_user", "rnd700x30", "rnd257x100_dead"])
+def test_class_table_ragged_kernel_vs_oracle(case):
+    """k_ragged<.., cls>: ragged lines over a mid-size DFA (class table <= 64 KB in LDS): every
+    mode, empty lines, lines ending at the end of the buffer, long lines, with and without the
+    length-bucketing pass."""
+    rng = np.random.default_rng(23)
+    if case == "uri_user":
+        blob, gen = load_dfa("uri_user"), W.alphabet_bytes
+    else:
+        n_st, n_cls = {"rnd700x30": (700, 30), "rnd257x100_dead": (258, 100)}[case]
+        blob = random_dfa(n_st, n_cls, 92, dead_frac=0.01 if case.endswith("dead") else 0.0,
+                          accept_frac=0.15)
+        gen = W.random_bytes
+    cpu = O.CpuOracle(blob)
+    for n in (3000, 20000):
+        lens = rng.geometric(1 / 90, n).astype(np.int64) - 1
+        lens[rng.integers(0, n, 5)] = rng.integers(2000, 5000, 5)
+        offsets = np.zeros(n + 1, dtype=np.uint64)
+        offsets[1:] = np.cumsum(lens)
+        data = gen(int(offsets[-1]), 41 + n).copy()
+        if case == "uri_user":
+            for k in range(0, data.size - 100, 600):
+                data[k:k + len(W.URI_USER_PLANT)] = np.frombuffer(W.URI_USER_PLANT, dtype=np.uint8)
+        for extra in ({}, {"no_bucketing": True}):
+            exe = one_amd.Executable(blob, **extra)
+            for sty in (4, 5):
+                er, es, ee = cpu.batch("match", sty, 0, data, offsets=offsets, threads=8)
+                r, s, e = one_amd.match_batch(exe, data, sty, 0, offsets=offsets)
+                assert one_amd.last_kernel().startswith("k_ragged<") and \
+                    one_amd.last_kernel().endswith("cls>"), one_amd.last_kernel()
+                assert np.array_equal(r, er), (case, n, sty)
+                assert np.array_equal(s, es) and np.array_equal(e, ee), (case, n, sty)
+                r, _, e = one_amd.match_batch(exe, data, sty, 0, offsets=offsets, want_start=False)
+                assert np.array_equal(r, er) and np.array_equal(e, ee)
+                assert np.array_equal(one_amd.check_batch(exe, data, sty, 0, offsets=offsets),
+                                      cpu.batch("check", sty, 0, data, offsets=offsets, threads=8)[0])
+
+
 def test_tune_reranks_hot_rows_results_unchanged():
     """redgpu_dfa_tune: visits counted on a sample of URL-bearing text re-rank the hot rows;
     outputs stay bit-exact, the share of the walk served from LDS goes up (measured on held-out

@@ -13,12 +13,19 @@ from golden_util import load_dfa, CONFIG_DFAS
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-HOT_BIAS = len(sys.argv) > 3 and sys.argv[3] == "hot"   # big DFAs, block-multiple strides
+HOT_BIAS = len(sys.argv) > 3 and sys.argv[3] in ("hot", "cls")  # big DFAs, block-multiple strides
+CLS_BIAS = len(sys.argv) > 3 and sys.argv[3] == "cls"           # ... of the class-table size
 rng = np.random.default_rng(seed)
 ALPHA = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz0123456789 ./:-_=&?%@[]", dtype=np.uint8)
 
 
 def make_dfa():
+    if CLS_BIAS:
+        n = int(rng.choice([257, 300, 700, 1300, 2000]))
+        c = int(rng.choice([2, 7, 25, 40, 100, 127]))
+        s = int(rng.integers(0, 1 << 30))
+        dead = float(rng.choice([0.0, 0.002, 0.02]))
+        return "rnd(%d,%d,%d,dead=%.3f)" % (n, c, s, dead), random_dfa(n, c, s, dead_frac=dead, accept_frac=0.2)
     if HOT_BIAS:
         k = int(rng.integers(0, 4))
         if k == 0:
@@ -92,13 +99,14 @@ for case in range(cases):
     shape, nbytes = make_lines()
     data = make_data(nbytes, name)
     flags = {}
-    for f, p in ((("force_generic", 0.05), ("force_global", 0.0), ("force_hot", 0.8),
+    for f, p in ((("force_generic", 0.05), ("no_bucketing", 0.3), ("force_stream", 0.5)) if CLS_BIAS else
+                 (("force_generic", 0.05), ("force_global", 0.0), ("force_hot", 0.8),
                   ("no_bucketing", 0.3), ("force_stream", 0.7)) if HOT_BIAS else
                  (("force_generic", 0.15), ("force_global", 0.15), ("force_hot", 0.25),
                   ("no_bucketing", 0.2), ("force_stream", 0.3))):
         if rng.random() < p:
             flags[f] = True
-    if rng.random() < 0.3:
+    if rng.random() < 0.3 and not CLS_BIAS:
         flags["lds_table_max"] = int(rng.choice([8 * 256, 40 * 256, 100 * 256, 20000, 70000]))
     try:
         exe = one_amd.Executable(blob, **flags)

@@ -1085,7 +1085,7 @@ def test_stateful_matcher_on_gpu():
     assert np.array_equal(res3.cpu().numpy(), exp3)
 
 
-@pytest.mark.parametrize("mode", ["general", "hot"])
+@pytest.mark.parametrize("mode", ["general", "hot", "cls"])
 def test_differential_fuzz_smoke(mode):
     """scripts/fuzz_gpu.py (random DFAs x line shapes x verbs x styles x placement / kernel flags
     vs the oracle), a short fixed-seed run of each bias; the open-ended campaign is run by hand."""
@@ -1094,7 +1094,7 @@ def test_differential_fuzz_smoke(mode):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "scripts", "fuzz_gpu.py"), "80", "11"]
-    if mode == "hot":
-        cmd.append("hot")
+    if mode != "general":
+        cmd.append(mode)
     out = subprocess.run(cmd, capture_output=True, text=True, cwd=root)
     assert out.returncode == 0 and "fuzz ok" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]

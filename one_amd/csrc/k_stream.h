@@ -496,11 +496,19 @@ k_stream(DevDfa d, Batch io) {
   }
 }
 
-// the HOT / CLS forms of the same launch (512 threads only)
-template <int MODE, int TABK = kTabHot>
-hipError_t launchStreamHot(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
-                           hipStream_t stream) {
-  constexpr int THREADS = kStreamThreads;
+// Few lines (fewer 1024-line tiles than CUs - BASELINE configs[4]: 65,536 x 64 KiB): 512-line
+// tiles of 256 threads put the lines on twice as many CUs.  Such a batch is bound by the LDS
+// latency of one line's dependent chain, not by throughput: 1.16 -> 1.63 TB/s, where the same
+// bytes cut into 2^20 lines run at 3.5 TB/s.
+inline bool fewLines(const Batch &b, const LaunchCfg &cfg) {
+  return (b.n + uint64_t(kStreamThreads) * kStreamChains - 1) /
+             (uint64_t(kStreamThreads) * kStreamChains) < uint64_t(cfg.numCUs);
+}
+
+// the HOT / CLS forms of the same launch
+template <int MODE, int TABK, int THREADS>
+hipError_t launchStreamHotT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
+                            hipStream_t stream) {
   const uint64_t linesPerTile = uint64_t(THREADS) * kStreamChains;
   const uint64_t tiles = (b.n + linesPerTile - 1) / linesPerTile;
   const uint64_t blocks = tiles < uint64_t(cfg.numCUs) ? tiles : uint64_t(cfg.numCUs);
@@ -511,6 +519,13 @@ hipError_t launchStreamHot(const DevDfa &d, const Batch &b, const LaunchCfg &cfg
     hipLaunchKernelGGL((k_stream<MODE, 1, THREADS, TABK>), dim3(uint32_t(blocks)), dim3(THREADS),
                        0, stream, d, b);
   return hipGetLastError();
+}
+
+template <int MODE, int TABK = kTabHot>
+hipError_t launchStreamHot(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
+                           hipStream_t stream) {
+  if (fewLines(b, cfg)) return launchStreamHotT<MODE, TABK, 256>(d, b, cfg, stream);
+  return launchStreamHotT<MODE, TABK, kStreamThreads>(d, b, cfg, stream);
 }
 
 template <int MODE, int THREADS>
@@ -537,7 +552,8 @@ hipError_t launchStreamT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
     const int v = e ? atoi(e) : kStreamThreads;
     return (v == 256 || v == 1024) ? v : 512;
   }();
-  if (threads == 256) return launchStreamTT<MODE, 256>(d, b, cfg, stream);
+  if (threads == 256 || (threads == 512 && fewLines(b, cfg)))
+    return launchStreamTT<MODE, 256>(d, b, cfg, stream);
   if (threads == 1024) return launchStreamTT<MODE, 1024>(d, b, cfg, stream);
   return launchStreamTT<MODE, 512>(d, b, cfg, stream);
 }

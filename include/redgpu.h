@@ -65,6 +65,8 @@ typedef struct redgpu_opts {
                                      bucketing them by length first (tests, tuning) */
 #define REDGPU_F_FORCE_STREAM 16u /* whole-line streaming kernels even for a DFA flagged
                                      early_death (tests, tuning) */
+#define REDGPU_F_NO_CHUNKING  32u /* never cut long lines into speculatively walked chunks */
+#define REDGPU_F_FORCE_CHUNKING 64u /* ... or always, whatever the DFA looks like (tests) */
 #define REDGPU_F_FORCE_HOT     4u /* a table too big for LDS always gets hot rows in LDS, even
                                      when the visit model finds no locality (tests, tuning) */
 
@@ -101,6 +103,8 @@ typedef struct redgpu_info {
   uint32_t early_death;   /* 1 if the same model sees most walks reach a pure dead end within 16
                              bytes (an anchored DFA on arbitrary text): such DFAs keep the
                              early-exit kernels */
+  uint32_t forgetful;     /* 1 if the model's walk is back in the initial state >= 70 % of the
+                             time: long lines may be cut into speculatively walked chunks */
   uint32_t image_refs;    /* handles currently sharing this handle's device image (the loader
                              cache: same blob + device + build options -> one repack, one upload) */
 } redgpu_info;

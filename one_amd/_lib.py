@@ -12,6 +12,7 @@ HEADER = os.path.join(os.path.dirname(HERE), "include", "redgpu.h")
 OK, EAPI, EEXEC, ELIMIT, EHIP = 0, -1, -2, -3, -5
 DEVICE_CURRENT, DEVICE_NONE = -1, -2
 F_FORCE_GENERIC, F_FORCE_GLOBAL, F_FORCE_HOT, F_NO_BUCKETING, F_FORCE_STREAM = 1, 2, 4, 8, 16
+F_NO_CHUNKING, F_FORCE_CHUNKING = 32, 64
 
 
 class Opts(C.Structure):
@@ -27,7 +28,7 @@ class Info(C.Structure):
                 ("max_result", C.c_int32), ("device", C.c_int32), ("checksum", C.c_uint32),
                 ("fast_path", C.c_uint32), ("n_hot", C.c_uint32), ("hot_lo", C.c_uint32),
                 ("hot_coverage_ppm", C.c_uint32), ("early_death", C.c_uint32),
-                ("image_refs", C.c_uint32)]
+                ("forgetful", C.c_uint32), ("image_refs", C.c_uint32)]
 
 
 def build(force: bool = False) -> str:

@@ -280,6 +280,7 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
       if (step == 15) img.earlyDeath = died > 0.5;
       p.swap(q);
     }
+    img.forgetful = p[rawInit] >= 0.7;
     if (measured && measured->size() == stateCnt) {
       img.tuned = true;
       // observed visits decide; the model (scaled far below one observed visit) breaks ties

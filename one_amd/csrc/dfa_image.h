@@ -72,6 +72,9 @@ struct DfaImage {
   // 2 x nClasses); clsBytes = 256 + rows, rounded up to 16.  0 = not built.
   uint32_t clsOff = 0, clsRowBytes = 0, clsBytes = 0;
   uint32_t hotCoveragePpm = 0;    // modelled share of visits landing on hot rows
+  bool     forgetful = false;     // the model's walk is back in the initial state most of the
+                                  // time (>= 70 % of its mass after 64 bytes): chunks of a line
+                                  // may be walked from the initial state as a guess (k_chunk.h)
   bool     tuned = false;         // the hot rows were ranked by observed visits (redgpu_dfa_tune)
   bool     earlyDeath = false;    // the model's walk is in a pure dead end within 16 bytes
                                   // more often than not (anchored DFA on arbitrary text)

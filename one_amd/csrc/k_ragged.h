@@ -276,6 +276,7 @@ k_ragged(DevDfa d, Batch io) {
     }
     if (!CLS && threadIdx.x < 256) ldsRes[threadIdx.x] = myRes;
   }
+  asm volatile("" : : "v"(tab) : "memory");  // the table is read from inline asm: see k_stream.h
   __syncthreads();
 
   const uint64_t total = io.offsets[io.n];

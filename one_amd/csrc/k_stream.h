@@ -35,6 +35,10 @@ enum StreamMode : int {
   kSmFull = 4,          // check<styFull> / match<styFull> without start
   kSmAdvance = 5,       // StatefulMatcher chunk: kSmFull's walk, state[] read at the first block
                         // of a line and written back after the last (include/Matcher.h:770-792)
+  kSmChunk = 6,         // one CHUNK of a long line (k_chunk.h): kSmLastStartEnd's bookkeeping from
+                        // an entry state (state[] in / out), raw records out instead of an Outcome:
+                        // result[] = state of the last accept or -1, end[] = its chunk-relative
+                        // end (0 = none), start[] = last "left the initial state" position + 1
 };
 
 struct StreamBook {
@@ -70,7 +74,7 @@ __device__ __forceinline__ void streamStep(uint32_t (&s)[2], const uint32_t (&w)
                                            uint32_t init) {
   uint32_t a[2], t[2];
   uint64_t m[2], l[2];
-  if constexpr (MODE == kSmLastStartEnd) {
+  if constexpr ((MODE == kSmLastStartEnd || MODE == kSmChunk)) {
     asm volatile(RS_PERM(0) RS_PERM(1) RS_READ(0) RS_READ(1)
                  RS_CMPA(0) RS_CMPA(1) RS_CMPI(0) RS_CMPI(1)
                  RS_ACC(0) RS_ACC(1) RS_END(0) RS_END(1)
@@ -140,7 +144,7 @@ __device__ __forceinline__ void streamStepCls(uint32_t (&s)[2], const uint32_t (
                                               uint64_t (&isI)[2], uint32_t T, uint32_t init) {
   uint32_t a[2], t[2];
   uint64_t m[2], l[2];
-  if constexpr (MODE == kSmLastStartEnd) {
+  if constexpr ((MODE == kSmLastStartEnd || MODE == kSmChunk)) {
     asm volatile(RC_ADD(0) RC_ADD(1) RC_READ(0) RC_READ(1)
                  RS_CMPA(0) RS_CMPA(1) RS_CMPI(0) RS_CMPI(1)
                  RS_ACC(0) RS_ACC(1) RS_END(0) RS_END(1)
@@ -229,8 +233,8 @@ template <int MODE>
 __device__ __noinline__ SlowBook slowHalf(const DevDfa &d, const uint8_t *tab8, const uint8_t *p,
                                           uint32_t off, SlowBook in) {
   uint32_t st = in.st, accS = in.accS, endv = in.endv, startv = in.startv;
-  constexpr bool kAcc = MODE == kSmLastStartEnd || MODE == kSmLastEnd;
-  constexpr bool kStart = MODE == kSmLastStartEnd || MODE == kSmFullStart;
+  constexpr bool kAcc = (MODE == kSmLastStartEnd || MODE == kSmChunk) || MODE == kSmLastEnd;
+  constexpr bool kStart = (MODE == kSmLastStartEnd || MODE == kSmChunk) || MODE == kSmFullStart;
   const uint16_t *cls = reinterpret_cast<const uint16_t *>(d.table);
   const uint8_t *eq = d.equivLeader;
   // the block comes back in four 16-byte requests (it is still in L1/L2), not 64 byte loads:
@@ -269,8 +273,8 @@ k_stream(DevDfa d, Batch io) {
   constexpr bool EARLY = true;  // first input block requested before the table barrier (-2 %)
   constexpr uint32_t BLK = 64 * HALVES;
   constexpr int CH = kStreamChains;
-  constexpr bool kAcc = MODE == kSmLastStartEnd || MODE == kSmLastEnd;
-  constexpr bool kStart = MODE == kSmLastStartEnd || MODE == kSmFullStart;
+  constexpr bool kAcc = (MODE == kSmLastStartEnd || MODE == kSmChunk) || MODE == kSmLastEnd;
+  constexpr bool kStart = (MODE == kSmLastStartEnd || MODE == kSmChunk) || MODE == kSmFullStart;
   __shared__ __align__(16) uint8_t lds[kStreamTabBytes + 1024];  // table at LDS offset 0
   uint8_t *tab = lds;
   int32_t *ldsRes = reinterpret_cast<int32_t *>(lds + kStreamTabBytes);
@@ -321,7 +325,7 @@ k_stream(DevDfa d, Batch io) {
 #pragma unroll
       for (int c = 0; c < CH; ++c) b[c].p[k] = reinterpret_cast<const uint4 *>(p[c])[k];
     }
-    if (MODE == kSmAdvance) {
+    if (MODE == kSmAdvance || MODE == kSmChunk) {
       // unconditional like the data (every block re-requests its line's state; only the first
       // block of a line uses it) so the in-order vmcnt counts stay exact
 #pragma unroll
@@ -363,6 +367,10 @@ k_stream(DevDfa d, Batch io) {
     }
     if (!CLS && threadIdx.x < 256) ldsRes[threadIdx.x] = myRes;
   }
+  // The byte steps read this table from inline asm only.  Unless its address visibly reaches an
+  // asm statement the compiler may treat the array as never read and drop the stores above -
+  // it did, in the one mode (kSmChunk) that has no C++ read of `lds` left.
+  asm volatile("" : : "v"(tab) : "memory");
   __syncthreads();
 
   uint32_t s[CH], accS[CH], endv[CH], startv[CH];
@@ -380,15 +388,22 @@ k_stream(DevDfa d, Batch io) {
         s[c] = init; accS[c] = 0; endv[c] = 0; startv[c] = 0;
         mA[c] = ~0ull; mB[c] = ~0ull;
         g[c] = kNoState;
-        if (MODE == kSmAdvance && !IDXD) s[c] = blk[c].st < d.nStates ? blk[c].st : init;
-        if (MODE == kSmAdvance && CLS) s[c] = toHot(blk[c].st < d.nStates ? blk[c].st : d.init);
-        if (MODE == kSmAdvance && HOT) {
+        constexpr bool kStateIn = MODE == kSmAdvance || MODE == kSmChunk;
+        if (MODE == kSmChunk) startv[c] = kNoState;  // "no such event in this chunk"
+        if (kStateIn && !IDXD) s[c] = blk[c].st < d.nStates ? blk[c].st : init;
+        if (kStateIn && CLS) s[c] = toHot(blk[c].st < d.nStates ? blk[c].st : d.init);
+        if (kStateIn && HOT) {
           const uint32_t st = blk[c].st < d.nStates ? blk[c].st : d.init;
           s[c] = toHot(st);
           g[c] = s[c] != 255u ? kNoState : st;
         } else if (HOT && init == 0x1ffu) {
           s[c] = 255u;
           g[c] = d.init;
+        }
+        if (MODE == kSmChunk) {
+          // the first step's "was in the initial state" is a fact about the ENTRY state here
+          mA[c] = __builtin_amdgcn_ballot_w64(s[c] == init);
+          mB[c] = mA[c];
         }
       }
     }
@@ -476,6 +491,13 @@ k_stream(DevDfa d, Batch io) {
           } else {
             rr = s[c] >= firstAccept ? ldsRes[s[c]] : 0;
             en = lineLen;
+          }
+          if (MODE == kSmChunk) {
+            io.state[ln] = sG;
+            io.result[ln] = endv[c] ? int32_t(accS[c]) : -1;
+            io.end[ln] = endv[c];
+            io.start[ln] = uint64_t(startv[c] + 1u);  // kNoState + 1 wraps to 0 = none
+            continue;
           }
           io.result[ln] = rr;
           if (MODE == kSmAdvance) io.state[ln] = sG;

@@ -30,6 +30,7 @@ struct DevDfa {
   uint32_t clsOff, clsRowBytes, clsBytes;  // streaming form of a <= 64 KB class table, or 0
   uint32_t earlyDeath;           // the visit model sees walks die within 16 bytes
   uint32_t tuned;                // hot rows ranked by observed visits
+  uint32_t forgetful;            // the walk is mostly in the initial state (k_chunk.h)
   // start bytes for scan / search (dfa_image.h): packed members, count (0xff = no filter)
   uint32_t startLeadWord, startLeadCount, startFreeWord, startFreeCount;
   uint32_t start2LeadWord, start2LeadCount, start2FreeWord, start2FreeCount;
@@ -55,6 +56,8 @@ struct LaunchCfg {
   int forceGeneric;
   int noBucketing = 0;  // k_ragged: keep lines in input order (REDGPU_F_NO_BUCKETING)
   int forceStream = 0;  // whole-line kernels even for early-death DFAs (REDGPU_F_FORCE_STREAM)
+  int noChunking = 0;   // never cut long lines into speculative chunks (REDGPU_F_NO_CHUNKING)
+  int forceChunking = 0; // ... or whenever the shape allows, whatever the DFA (REDGPU_F_FORCE_CHUNKING)
 };
 
 // Launches the kernel for (verb, style, doLeader) on `stream`; returns hipSuccess or the

@@ -1271,6 +1271,8 @@ hipError_t setLds(K kernel, size_t bytes) {
                              hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
 }
 
+#include "k_chunk.h"
+
 template <int KIND>
 hipError_t launchGeneric(const DevDfa &d, const Batch &b, int verb, int style, int lead,
                          const LaunchCfg &cfg, hipStream_t stream) {
@@ -1635,6 +1637,34 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
   // Streaming kernel: styles Last / Full on lines that are whole 64-byte blocks.
   const bool streamOk = fixedOk && (style == kStyLast || style == kStyFull) &&
                         b.stride % 64 == 0 && d.tableBytes <= kStreamTabBytes && d.nStates <= 256;
+  // The same streaming walk for DFAs too big for LDS: hot rows as a one-byte-indexed table,
+  // cold excursions re-walked per 64-byte half-block (k_stream.h, HOT).
+  const bool hotStreamOk = !cfg.forceGeneric && !dying && hotStreamEligible(d) && !b.offsets &&
+                           (verb == kCheck || verb == kMatch) &&
+                           (style == kStyLast || style == kStyFull) && b.stride >= 64 &&
+                           b.stride % 64 == 0 && b.stride < (1ull << 31) &&
+                           (reinterpret_cast<uintptr_t>(b.data) % 16) == 0 &&
+                           !(lead && verb == kCheck);
+  // Few long lines over a DFA that forgets its past: chunks of every line walked at once from
+  // the initial state as a guess, wrong guesses re-walked (k_chunk.h)
+  if ((streamOk || hotStreamOk) && !cfg.noChunking && (d.forgetful || cfg.forceChunking) &&
+      (fewLines(b, cfg) || cfg.forceChunking)) {
+    const uint32_t m = chunksPerLine(b, cfg);
+    if (m) {
+      Batch sb = b;
+      if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
+      *kernelName = d.tableKind == REDGPU_TAB_HOT_ROWS ? "k_stream<chunk,hot>+k_chunk"
+                                                       : "k_stream<chunk>+k_chunk";
+      hipError_t e = launchChunked(d, sb, m, style, cfg, stream);
+      if (e != hipSuccess) return e;
+      if (lead) {
+        hipLaunchKernelGGL(k_leader_filter, dim3(uint32_t(cfg.numCUs) * 8), dim3(256), 0, stream,
+                           d, b);
+        return hipGetLastError();
+      }
+      return hipSuccess;
+    }
+  }
   if (streamOk) {
     hipError_t e;
     Batch sb = b;
@@ -1654,14 +1684,6 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
     }
     return hipSuccess;
   }
-  // The same streaming walk for DFAs too big for LDS: hot rows as a one-byte-indexed table,
-  // cold excursions re-walked per 64-byte half-block (k_stream.h, HOT).
-  const bool hotStreamOk = !cfg.forceGeneric && !dying && hotStreamEligible(d) && !b.offsets &&
-                           (verb == kCheck || verb == kMatch) &&
-                           (style == kStyLast || style == kStyFull) && b.stride >= 64 &&
-                           b.stride % 64 == 0 && b.stride < (1ull << 31) &&
-                           (reinterpret_cast<uintptr_t>(b.data) % 16) == 0 &&
-                           !(lead && verb == kCheck);
   if (hotStreamOk) {
     hipError_t e;
     Batch sb = b;

@@ -114,7 +114,9 @@ int runDev(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint8
   Batch b{data, offsets, stride, n, result, start, end};
   LaunchCfg cfg{dfa->numCUs, (dfa->flags & REDGPU_F_FORCE_GENERIC) ? 1 : 0,
                 (dfa->flags & REDGPU_F_NO_BUCKETING) ? 1 : 0,
-                (dfa->flags & REDGPU_F_FORCE_STREAM) ? 1 : 0};
+                (dfa->flags & REDGPU_F_FORCE_STREAM) ? 1 : 0,
+                (dfa->flags & REDGPU_F_NO_CHUNKING) ? 1 : 0,
+                (dfa->flags & REDGPU_F_FORCE_CHUNKING) ? 1 : 0};
   const char *name = "";
   hipError_t e = launchBatch(dfa->im->dev, b, verb, style, doLeader ? 1 : 0, cfg, stream, &name);
   tlsKernel = name;
@@ -254,6 +256,7 @@ int uploadImage(SharedImage *im) {
   d.clsRowBytes = img.clsRowBytes;
   d.clsBytes = img.clsBytes;
   d.tuned = img.tuned ? 1 : 0;
+  d.forgetful = img.forgetful ? 1 : 0;
   d.startLeadWord = img.startLeadWord;
   d.startLeadCount = img.startLeadCount;
   d.startFreeWord = img.startFreeWord;
@@ -408,6 +411,7 @@ int redgpu_dfa_info(const redgpu_dfa *h, redgpu_info *out) {
   out->hot_lo = img.hotLo;
   out->hot_coverage_ppm = img.hotCoveragePpm;
   out->early_death = img.earlyDeath ? 1 : 0;
+  out->forgetful = img.forgetful ? 1 : 0;
   out->image_refs = uint32_t(h->im.use_count());
   return REDGPU_OK;
 }

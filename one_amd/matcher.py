@@ -77,7 +77,7 @@ class Executable:
 
     def __init__(self, serialized: bytes, device=None, *, force_generic=False,
                  force_global=False, force_hot=False, no_bucketing=False,
-                 force_stream=False,
+                 force_stream=False, no_chunking=False, force_chunking=False,
                  lds_table_max=0):
         if serialized is None or len(serialized) == 0:
             raise RedExceptApi("serialized dfa string_view is empty")  # Executable.cpp:66
@@ -89,7 +89,9 @@ class Executable:
                   (_lib.F_FORCE_GLOBAL if force_global else 0) | \
                   (_lib.F_FORCE_HOT if force_hot else 0) | \
                   (_lib.F_NO_BUCKETING if no_bucketing else 0) | \
-                  (_lib.F_FORCE_STREAM if force_stream else 0)
+                  (_lib.F_FORCE_STREAM if force_stream else 0) | \
+                  (_lib.F_NO_CHUNKING if no_chunking else 0) | \
+                  (_lib.F_FORCE_CHUNKING if force_chunking else 0)
         self._h = C.c_void_p()
         blob = bytes(serialized)
         _check(_lib.lib().redgpu_dfa_create(blob, len(blob), C.byref(o), C.byref(self._h)))

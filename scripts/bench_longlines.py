@@ -21,6 +21,11 @@ d = torch.randint(0, 256, (n * L,), dtype=torch.uint8, device="cuda")
 if "syn4k" in sys.argv:
     t("configs[4] full: SYN-4K 65536 x 64 KiB", one_amd.Executable(random_dfa(4097, 256, 5, accept_frac=0.1)), d, L, n, it=2)
 t("configs[4] alt: URI-V6 65536 x 64 KiB", one_amd.Executable(load_dfa("uri_v6")), d, L, n)
+t("  same, no chunking", one_amd.Executable(load_dfa("uri_v6"), no_chunking=True), d, L, n)
+t("URI-V6 4096 x 64 KiB", one_amd.Executable(load_dfa("uri_v6")), d, L, 4096)
+t("  same, no chunking", one_amd.Executable(load_dfa("uri_v6"), no_chunking=True), d, L, 4096)
+t("URI-D 16384 x 64 KiB", one_amd.Executable(load_dfa("uri")), d, L, 16384)
+t("  same, no chunking", one_amd.Executable(load_dfa("uri"), no_chunking=True), d, L, 16384)
 t("SYN-256 65536 x 64 KiB", one_amd.Executable(load_dfa("syn256")), d, L, n)
 t("SYN-256 16384 x 64 KiB", one_amd.Executable(load_dfa("syn256")), d, L, n // 4)
 t("SYN-256 same bytes as 2^20 x 4 KiB", one_amd.Executable(load_dfa("syn256")), d, 4096, 1 << 20)

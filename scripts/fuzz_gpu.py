@@ -101,9 +101,9 @@ for case in range(cases):
     flags = {}
     for f, p in ((("force_generic", 0.05), ("no_bucketing", 0.3), ("force_stream", 0.5)) if CLS_BIAS else
                  (("force_generic", 0.05), ("force_global", 0.0), ("force_hot", 0.8),
-                  ("no_bucketing", 0.3), ("force_stream", 0.7)) if HOT_BIAS else
+                  ("no_bucketing", 0.3), ("force_stream", 0.7), ("force_chunking", 0.4)) if HOT_BIAS else
                  (("force_generic", 0.15), ("force_global", 0.15), ("force_hot", 0.25),
-                  ("no_bucketing", 0.2), ("force_stream", 0.3))):
+                  ("no_bucketing", 0.2), ("force_stream", 0.3), ("force_chunking", 0.3))):
         if rng.random() < p:
             flags[f] = True
     if rng.random() < 0.3 and not CLS_BIAS:

@@ -406,6 +406,48 @@ def test_class_table_ragged_kernel_vs_oracle(case):
                                       cpu.batch("check", sty, 0, data, offsets=offsets, threads=8)[0])
 
 
+@pytest.mark.parametrize("case", ["uri", "dotstar_err", "uri_v6", "syn256_forced", "newyork"])
+def test_speculative_chunking_vs_oracle(case):
+    """k_chunk.h: few long lines cut into chunks walked at once from the initial state, wrong
+    guesses re-walked round by round.  Loose-start DFAs (mostly right guesses), a dense random
+    one with chunking forced (every guess wrong: all rounds, then the serial finish), matches
+    that straddle chunk borders, Last and Full, check, the leader filter."""
+    name = case.replace("_forced", "")
+    blob = load_dfa(name)
+    kw = {"force_chunking": True} if case.endswith("forced") else {}
+    exe, cpu = one_amd.Executable(blob, **kw), O.CpuOracle(blob)
+    rng = np.random.default_rng(51)
+    for n, L in ((5, 65536), (64, 16384), (300, 4096), (1, 8192)):
+        if name == "syn256":
+            data = W.random_bytes(n * L, 61).copy()
+        else:
+            data = W.alphabet_bytes(n * L, 61).copy()
+            plants = {"uri": W.URI_PLANT, "uri_v6": W.URI_PLANT, "dotstar_err": b" an error: x ",
+                      "newyork": b"I love New York."}[name]
+            p = np.frombuffer(plants, dtype=np.uint8)
+            for k in range(0, data.size - 200, 777):   # 777: lands on and across chunk borders
+                data[k:k + len(p)] = p
+            # a match ending exactly at a line's last byte and one starting at its first
+            data[L - len(p):L] = p
+            data[(n - 1) * L:(n - 1) * L + len(p)] = p
+        for sty in (4, 5):
+            er, es, ee = cpu.batch("match", sty, 0, data, stride=L, n=n, threads=8)
+            r, s, e = one_amd.match_batch(exe, data, sty, 0, stride=L, n=n)
+            assert "k_chunk" in one_amd.last_kernel(), one_amd.last_kernel()
+            assert np.array_equal(r, er), (case, n, L, sty)
+            assert np.array_equal(s, es) and np.array_equal(e, ee), (case, n, L, sty)
+            r, _, e = one_amd.match_batch(exe, data, sty, 1, stride=L, n=n, want_start=False)
+            assert np.array_equal(r, er) and np.array_equal(e, ee)
+            assert np.array_equal(one_amd.check_batch(exe, data, sty, 0, stride=L, n=n),
+                                  cpu.batch("check", sty, 0, data, stride=L, n=n, threads=8)[0])
+        # the same through the whole-line kernels
+        plain = one_amd.Executable(blob, no_chunking=True)
+        r2, s2, e2 = one_amd.match_batch(plain, data, 4, 0, stride=L, n=n)
+        assert "k_chunk" not in one_amd.last_kernel()
+        er, es, ee = cpu.batch("match", 4, 0, data, stride=L, n=n, threads=8)
+        assert np.array_equal(r2, er) and np.array_equal(s2, es) and np.array_equal(e2, ee)
+
+
 def test_tune_reranks_hot_rows_results_unchanged():
     """redgpu_dfa_tune: visits counted on a sample of URL-bearing text re-rank the hot rows;
     outputs stay bit-exact, the share of the walk served from LDS goes up (measured on held-out

@@ -258,6 +258,10 @@ inline hipError_t launchChunked(const DevDfa &d, const Batch &b, uint32_t m, int
   // the entry-state guesses
   if (d.tableKind == REDGPU_TAB_HOT_ROWS)
     e = launchChunkGuess<REDGPU_TAB_HOT_ROWS>(d, b, m, chunkLen, cb, cfg, stream);
+  else if (d.tableKind == REDGPU_TAB_LDS_CLASS_U16)
+    e = launchChunkGuess<REDGPU_TAB_LDS_CLASS_U16>(d, b, m, chunkLen, cb, cfg, stream);
+  else if (d.tableKind == REDGPU_TAB_LDS_FUSED_U16)
+    e = launchChunkGuess<REDGPU_TAB_LDS_FUSED_U16>(d, b, m, chunkLen, cb, cfg, stream);
   else
     e = launchChunkGuess<REDGPU_TAB_LDS_FUSED_U8>(d, b, m, chunkLen, cb, cfg, stream);
   if (e != hipSuccess) return e;
@@ -266,10 +270,16 @@ inline hipError_t launchChunked(const DevDfa &d, const Batch &b, uint32_t m, int
   cbatch.state = cb.st;
   if (d.tableKind == REDGPU_TAB_HOT_ROWS)
     e = launchStreamHot<kSmChunk, kTabHot>(d, cbatch, cfg, stream);
-  else
+  else if (d.tableKind == REDGPU_TAB_LDS_FUSED_U8)
     e = launchStreamT<kSmChunk>(d, cbatch, cfg, stream);
+  else
+    e = launchStreamHot<kSmChunk, kTabCls>(d, cbatch, cfg, stream);
   if (e != hipSuccess) return e;
   if (d.tableKind == REDGPU_TAB_HOT_ROWS)
     return launchChunkTail<REDGPU_TAB_HOT_ROWS>(d, b, m, chunkLen, style, cb, cfg, stream);
+  if (d.tableKind == REDGPU_TAB_LDS_CLASS_U16)
+    return launchChunkTail<REDGPU_TAB_LDS_CLASS_U16>(d, b, m, chunkLen, style, cb, cfg, stream);
+  if (d.tableKind == REDGPU_TAB_LDS_FUSED_U16)
+    return launchChunkTail<REDGPU_TAB_LDS_FUSED_U16>(d, b, m, chunkLen, style, cb, cfg, stream);
   return launchChunkTail<REDGPU_TAB_LDS_FUSED_U8>(d, b, m, chunkLen, style, cb, cfg, stream);
 }

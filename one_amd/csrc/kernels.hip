@@ -1645,16 +1645,25 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
                            b.stride % 64 == 0 && b.stride < (1ull << 31) &&
                            (reinterpret_cast<uintptr_t>(b.data) % 16) == 0 &&
                            !(lead && verb == kCheck);
+  // ... and for mid-size DFAs whose class table fits 64 KB of LDS (two lookups per byte)
+  const bool clsStreamOk = !cfg.forceGeneric && !dying && clsStreamEligible(d) && !b.offsets &&
+                           (verb == kCheck || verb == kMatch) &&
+                           (style == kStyLast || style == kStyFull) && b.stride >= 64 &&
+                           b.stride % 64 == 0 && b.stride < (1ull << 31) &&
+                           (reinterpret_cast<uintptr_t>(b.data) % 16) == 0 &&
+                           !(lead && verb == kCheck);
   // Few long lines over a DFA that forgets its past: chunks of every line walked at once from
   // the initial state as a guess, wrong guesses re-walked (k_chunk.h)
-  if ((streamOk || hotStreamOk) && !cfg.noChunking && (d.forgetful || cfg.forceChunking) &&
+  if ((streamOk || hotStreamOk || clsStreamOk) && !cfg.noChunking &&
+      (d.forgetful || cfg.forceChunking) &&
       (fewLines(b, cfg) || cfg.forceChunking)) {
     const uint32_t m = chunksPerLine(b, cfg);
     if (m) {
       Batch sb = b;
       if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
       *kernelName = d.tableKind == REDGPU_TAB_HOT_ROWS ? "k_stream<chunk,hot>+k_chunk"
-                                                       : "k_stream<chunk>+k_chunk";
+                    : d.tableKind == REDGPU_TAB_LDS_FUSED_U8 ? "k_stream<chunk>+k_chunk"
+                                                             : "k_stream<chunk,cls>+k_chunk";
       hipError_t e = launchChunked(d, sb, m, style, cfg, stream);
       if (e != hipSuccess) return e;
       if (lead) {
@@ -1703,13 +1712,6 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
     }
     return hipSuccess;
   }
-  // ... and for mid-size DFAs whose class table fits 64 KB of LDS (two lookups per byte)
-  const bool clsStreamOk = !cfg.forceGeneric && !dying && clsStreamEligible(d) && !b.offsets &&
-                           (verb == kCheck || verb == kMatch) &&
-                           (style == kStyLast || style == kStyFull) && b.stride >= 64 &&
-                           b.stride % 64 == 0 && b.stride < (1ull << 31) &&
-                           (reinterpret_cast<uintptr_t>(b.data) % 16) == 0 &&
-                           !(lead && verb == kCheck);
   if (clsStreamOk) {
     hipError_t e;
     Batch sb = b;

@@ -8,14 +8,21 @@
 // over the renumbered device image of dfa_image.h (s < nPureDead <=> pureDeadEnd,
 // s >= firstAccept <=> result > 0, so the per-byte predicates are integer compares).
 //
-// Two families:
-//   k_generic<KIND>   any verb / style / doLeader / ragged or fixed lines / any table placement.
-//                     The correctness workhorse (and the path for DFAs that do not fit LDS).
-//   k_fixed<...>      the hot path of BASELINE.json: fixed-stride lines, fused [state][byte]
-//                     u8 table resident in LDS (one ds_read_u8 per input byte, no equivalence
-//                     lookup), several independent lines per lane for LDS-latency cover,
-//                     16-byte global loads, coalesced SoA result stores.  No MFMA: this is a
-//                     gather workload bounded by HBM input streaming and the LDS gather rate.
+// Map of this file and its includes (DESIGN.md section 4 has the measurements):
+//   k_stream.h   k_stream<MODE, HALVES, THREADS, TABK>: the hot path - fixed-stride lines that are
+//                whole 64-byte blocks, styles Last / Full of check / match, StatefulMatcher
+//                chunks; inline-asm byte step over a fused u8 table (<= 256 states), the hot-row
+//                table of a big DFA (sink + re-walk) or a class table of <= 64 KB in LDS.
+//   k_ragged.h   k_ragged<MODE, TABK>: the same walk over ragged lines (offsets[n+1]), the
+//                tail pad and the length-bucketing pre-pass.
+//   k_chunk.h    few long lines: chunks walked at once from guessed entry states, wrong guesses
+//                re-walked (speculative chunking).
+//   here         the lane functions (checkLane ... replaceLane: direct restatements of the
+//                reference's cores), k_generic<KIND, THREADS, VERB> and the list / rewrite
+//                kernels built on them (k_collect, k_matchall, k_replace, k_advance, k_visits),
+//                k_fixed (strides that are not whole blocks, early-exit styles), line splitting,
+//                and launchBatch: which kernel runs what.
+// No MFMA anywhere: this is a gather workload bounded by the LDS gather rate and HBM streaming.
 #include "kernels.h"
 
 #include <cstdlib>

@@ -246,7 +246,7 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
   const bool haveMeasured = measured && measured->size() == stateCnt;
   // a class table of <= 64 KB (<= 127 classes) has its own streaming form (k_stream cls: two
   // lookups per byte, no cold path, 2.3 TB/s on that same DFA and input) and stays where it is
-  const bool clsStream = nCls <= 127 && uint64_t(reach.size()) * nCls * 2u <= 65536u;
+  const bool clsStream = nCls <= 127 && uint64_t(reach.size()) * nCls * 2u <= 158720u - 256u;
   const bool wantHot = !forceGlobal && reach.size() > 256 && reach.size() <= 65536 &&
                        ldsTableMax >= 8u * 256u &&
                        (fitKind == REDGPU_TAB_HOT_ROWS ||
@@ -418,8 +418,10 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
   }
   }
   if (img.primaryBytes == 0) img.primaryBytes = uint32_t(img.table.size());
+  constexpr uint64_t kClsBigMax = 158720u - 256u;  // k_stream's big LDS array minus eq2
   if ((img.tableKind == REDGPU_TAB_LDS_CLASS_U16 || img.tableKind == REDGPU_TAB_LDS_FUSED_U16) &&
-      nCls <= 127 && uint64_t(img.nStates) * nCls * 2u <= 65536u) {
+      nCls <= 127 && uint64_t(img.nStates) * nCls * 2u <= kClsBigMax) {
+    img.clsIndexForm = uint64_t(img.nStates) * nCls * 2u > 65536u;
     img.clsRowBytes = nCls * 2u;
     img.clsOff = uint32_t((img.table.size() + 15u) & ~size_t(15));
     const uint32_t rows = img.nStates * img.clsRowBytes;
@@ -429,7 +431,8 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
     for (uint32_t b = 0; b < 256; ++b) base[b] = uint8_t(2u * img.equiv[b]);
     for (uint32_t i = 0; i < img.nStates; ++i)
       for (uint32_t c = 0; c < nCls; ++c) {
-        const uint16_t off = uint16_t(img.next[size_t(i) * nCls + c] * img.clsRowBytes);
+        const uint32_t t = img.next[size_t(i) * nCls + c];
+        const uint16_t off = uint16_t(img.clsIndexForm ? t : t * img.clsRowBytes);
         std::memcpy(base + 256 + size_t(i) * img.clsRowBytes + 2 * c, &off, 2);
       }
   }

@@ -71,6 +71,9 @@ struct DfaImage {
   // class), then nStates rows of nClasses u16 = byte offset of the target's row (clsRowBytes =
   // 2 x nClasses); clsBytes = 256 + rows, rounded up to 16.  0 = not built.
   uint32_t clsOff = 0, clsRowBytes = 0, clsBytes = 0;
+  // ... and above 64 KB (up to what LDS holds) the same blob in INDEX form: entries are plain
+  // state indices and the kernel multiplies (v_mad_u32_u24) instead of adding
+  bool clsIndexForm = false;
   uint32_t hotCoveragePpm = 0;    // modelled share of visits landing on hot rows
   bool     forgetful = false;     // the model's walk is back in the initial state most of the
                                   // time (>= 70 % of its mass after 64 bytes): chunks of a line

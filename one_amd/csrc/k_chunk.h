@@ -272,6 +272,8 @@ inline hipError_t launchChunked(const DevDfa &d, const Batch &b, uint32_t m, int
     e = launchStreamHot<kSmChunk, kTabHot>(d, cbatch, cfg, stream);
   else if (d.tableKind == REDGPU_TAB_LDS_FUSED_U8)
     e = launchStreamT<kSmChunk>(d, cbatch, cfg, stream);
+  else if (d.clsIndexForm)
+    e = launchStreamHot<kSmChunk, kTabClsBig>(d, cbatch, cfg, stream);
   else
     e = launchStreamHot<kSmChunk, kTabCls>(d, cbatch, cfg, stream);
   if (e != hipSuccess) return e;

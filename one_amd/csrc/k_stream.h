@@ -137,13 +137,68 @@ __device__ __forceinline__ void streamWalk16(const uint4 (&piece)[2], uint32_t (
 #define RC_ADD(c) "v_add_u32 %[a" #c "], %[s" #c "], %[k" #c "]\n\t"
 #define RC_READ(c) "ds_read_u16 %[t" #c "], %[a" #c "] offset:256\n\t"
 #define RC_I_CHAIN(c) [s##c] "v"(s[c]), [k##c] "v"(cls[c])
+// index form (tables above 64 KB): row = state x rowBytes
+#define RC_MAD(c) "v_mad_u32_u24 %[a" #c "], %[s" #c "], %[rowb], %[k" #c "]\n\t"
 
+// ds_read_u16 at a given address + the step's bookkeeping (the index form's second half)
+#define RC_I_READ(c) [s##c] "v"(s[c]), [a##c] "v"(a[c])
+#define RC_O_READ(c) [t##c] "=&v"(t[c])
 template <int MODE, int IDX>
+__device__ __forceinline__ void streamStepRead(uint32_t (&s)[2], const uint32_t (&a)[2],
+                                               uint32_t (&t)[2], StreamBook (&b)[2],
+                                               const uint64_t (&wasI)[2], uint64_t (&isI)[2],
+                                               uint32_t T, uint32_t init) {
+  uint64_t m[2], l[2];
+  if constexpr ((MODE == kSmLastStartEnd || MODE == kSmChunk)) {
+    asm volatile(RC_READ(0) RC_READ(1)
+                 RS_CMPA(0) RS_CMPA(1) RS_CMPI(0) RS_CMPI(1)
+                 RS_ACC(0) RS_ACC(1) RS_END(0) RS_END(1)
+                 RS_LEAVE(0) RS_LEAVE(1) RS_START(0) RS_START(1) RS_WAIT
+                 : RC_O_READ(0), RC_O_READ(1), RS_O_ACC(0), RS_O_ACC(1), RS_O_END(0),
+                   RS_O_END(1), RS_O_START(0), RS_O_START(1)
+                 : RC_I_READ(0), RC_I_READ(1), RS_I_START(0), RS_I_START(1), [T] "s"(T),
+                   [init] "s"(init), [idx] "n"(IDX)
+                 : "memory", "scc");
+  } else if constexpr (MODE == kSmLastEnd) {
+    asm volatile(RC_READ(0) RC_READ(1)
+                 RS_CMPA(0) RS_CMPA(1) "s_nop 0\n\t" RS_ACC(0) RS_ACC(1) RS_END(0) RS_END(1) RS_WAIT
+                 : RC_O_READ(0), RC_O_READ(1), RS_O_ACC(0), RS_O_ACC(1), RS_O_END(0), RS_O_END(1)
+                 : RC_I_READ(0), RC_I_READ(1), [T] "s"(T), [idx] "n"(IDX)
+                 : "memory");
+  } else if constexpr (MODE == kSmFullStart) {
+    asm volatile(RC_READ(0) RC_READ(1)
+                 RS_CMPI(0) RS_CMPI(1) "s_nop 0\n\t" RS_LEAVE(0) RS_LEAVE(1) RS_START(0) RS_START(1)
+                 RS_WAIT
+                 : RC_O_READ(0), RC_O_READ(1), RS_O_START(0), RS_O_START(1)
+                 : RC_I_READ(0), RC_I_READ(1), RS_I_START(0), RS_I_START(1), [init] "s"(init),
+                   [idx] "n"(IDX)
+                 : "memory", "scc");
+  } else {
+    asm volatile(RC_READ(0) RC_READ(1) RS_WAIT
+                 : RC_O_READ(0), RC_O_READ(1)
+                 : RC_I_READ(0), RC_I_READ(1)
+                 : "memory");
+  }
+}
+
+template <int MODE, int IDX, bool BIG>
 __device__ __forceinline__ void streamStepCls(uint32_t (&s)[2], const uint32_t (&cls)[2],
                                               StreamBook (&b)[2], const uint64_t (&wasI)[2],
-                                              uint64_t (&isI)[2], uint32_t T, uint32_t init) {
+                                              uint64_t (&isI)[2], uint32_t T, uint32_t init,
+                                              uint32_t rowb) {
   uint32_t a[2], t[2];
   uint64_t m[2], l[2];
+  if constexpr (BIG) {
+    // the address first (its own statement: one more input), then the shared read + bookkeeping
+    asm volatile(RC_MAD(0) RC_MAD(1)
+                 : [a0] "=&v"(a[0]), [a1] "=&v"(a[1])
+                 : [s0] "v"(s[0]), [s1] "v"(s[1]), [k0] "v"(cls[0]), [k1] "v"(cls[1]),
+                   [rowb] "s"(rowb));
+    streamStepRead<MODE, IDX>(s, a, t, b, wasI, isI, T, init);
+    s[0] = t[0];
+    s[1] = t[1];
+    return;
+  }
   if constexpr ((MODE == kSmLastStartEnd || MODE == kSmChunk)) {
     asm volatile(RC_ADD(0) RC_ADD(1) RC_READ(0) RC_READ(1)
                  RS_CMPA(0) RS_CMPA(1) RS_CMPI(0) RS_CMPI(1)
@@ -178,26 +233,27 @@ __device__ __forceinline__ void streamStepCls(uint32_t (&s)[2], const uint32_t (
   s[1] = t[1];
 }
 
-template <int MODE, int Q>
+template <int MODE, int Q, bool BIG>
 __device__ __forceinline__ void streamWalk16Cls(const uint4 (&piece)[2], uint32_t (&s)[2],
                                                 StreamBook (&b)[2], uint64_t (&mA)[2],
                                                 uint64_t (&mB)[2], uint32_t T, uint32_t init,
-                                                const uint8_t *eq2) {
+                                                const uint8_t *eq2, uint32_t rowb) {
   uint32_t cl[4][2];
 #define RC_WORD(K, FIELD)                                                                  \
   _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                          \
     cl[k][0] = eq2[(piece[0].FIELD >> (8 * k)) & 0xffu];                                   \
     cl[k][1] = eq2[(piece[1].FIELD >> (8 * k)) & 0xffu];                                   \
   }                                                                                        \
-  streamStepCls<MODE, 16 * Q + 4 * K + 0>(s, cl[0], b, mA, mB, T, init);                   \
-  streamStepCls<MODE, 16 * Q + 4 * K + 1>(s, cl[1], b, mB, mA, T, init);                   \
-  streamStepCls<MODE, 16 * Q + 4 * K + 2>(s, cl[2], b, mA, mB, T, init);                   \
-  streamStepCls<MODE, 16 * Q + 4 * K + 3>(s, cl[3], b, mB, mA, T, init);
+  streamStepCls<MODE, 16 * Q + 4 * K + 0, BIG>(s, cl[0], b, mA, mB, T, init, rowb);                   \
+  streamStepCls<MODE, 16 * Q + 4 * K + 1, BIG>(s, cl[1], b, mB, mA, T, init, rowb);                   \
+  streamStepCls<MODE, 16 * Q + 4 * K + 2, BIG>(s, cl[2], b, mA, mB, T, init, rowb);                   \
+  streamStepCls<MODE, 16 * Q + 4 * K + 3, BIG>(s, cl[3], b, mB, mA, T, init, rowb);
   RC_WORD(0, x) RC_WORD(1, y) RC_WORD(2, z) RC_WORD(3, w)
 #undef RC_WORD
 }
 
-constexpr int kTabFused = 0, kTabHot = 1, kTabCls = 2;
+constexpr int kTabFused = 0, kTabHot = 1, kTabCls = 2, kTabClsBig = 3;
+constexpr uint32_t kStreamBigLds = 158720;  // the class-table form above 64 KB: one workgroup per CU
 
 // =========================================================================================
 // k_stream<MODE, HALVES>: each lane pulls a whole block of its line - 128 bytes (HALVES = 2,
@@ -268,14 +324,16 @@ template <int MODE, int HALVES, int THREADS, int TABK = kTabFused>
 __global__ void __launch_bounds__(THREADS)
 k_stream(DevDfa d, Batch io) {
   constexpr bool HOT = TABK == kTabHot;
-  constexpr bool CLS = TABK == kTabCls;
+  constexpr bool BIG = TABK == kTabClsBig;   // class table above 64 KB, index form
+  constexpr bool CLS = TABK == kTabCls || BIG;
   constexpr bool IDXD = HOT || CLS;  // the walk's state values are not device state ids
-  constexpr bool EARLY = true;  // first input block requested before the table barrier (-2 %)
+  constexpr bool EARLY = !BIG;  // first input block requested before the table barrier (-2 %)
   constexpr uint32_t BLK = 64 * HALVES;
   constexpr int CH = kStreamChains;
   constexpr bool kAcc = (MODE == kSmLastStartEnd || MODE == kSmChunk) || MODE == kSmLastEnd;
   constexpr bool kStart = (MODE == kSmLastStartEnd || MODE == kSmChunk) || MODE == kSmFullStart;
-  __shared__ __align__(16) uint8_t lds[kStreamTabBytes + 1024];  // table at LDS offset 0
+  constexpr uint32_t kLdsBytes = BIG ? kStreamBigLds : kStreamTabBytes + 1024;
+  __shared__ __align__(16) uint8_t lds[kLdsBytes];  // table at LDS offset 0
   uint8_t *tab = lds;
   int32_t *ldsRes = reinterpret_cast<int32_t *>(lds + kStreamTabBytes);
 
@@ -283,16 +341,19 @@ k_stream(DevDfa d, Batch io) {
   // state gets an index no lane can hold)
   const uint32_t init =
       HOT ? (d.init - d.hotLo < d.nHot ? d.init - d.hotLo + d.hotShift : 0x1ffu)
-          : CLS ? d.init * d.clsRowBytes : d.init;
+          : (CLS && !BIG) ? d.init * d.clsRowBytes : d.init;
   const uint32_t firstAccept = HOT ? d.firstAccept - d.hotLo + d.hotShift
-                                   : CLS ? d.firstAccept * d.clsRowBytes : d.firstAccept;
+                                   : (CLS && !BIG) ? d.firstAccept * d.clsRowBytes
+                                                   : d.firstAccept;
   // HOT: global state id <-> hot index (255 = not hot; index 0 = dead when hotShift)
   auto toHot = [&](uint32_t st) -> uint32_t {
+    if (BIG) return st;
     if (CLS) return st * d.clsRowBytes;
     if (d.hotShift && st < d.nPureDead) return 0u;
     return st - d.hotLo < d.nHot ? st - d.hotLo + d.hotShift : 255u;
   };
   auto toGlobal = [&](uint32_t idx) -> uint32_t {
+    if (BIG) return idx;
     if (CLS) return idx / d.clsRowBytes;
     return (d.hotShift && idx == 0) ? 0u : d.hotLo + idx - d.hotShift;
   };
@@ -348,12 +409,15 @@ k_stream(DevDfa d, Batch io) {
       reinterpret_cast<const uint4 *>(d.table + (HOT ? d.hot8Off : CLS ? d.clsOff : 0u));
   const uint32_t n16 = HOT ? kStreamTabBytes / 16 : CLS ? d.clsBytes / 16 : d.tableBytes / 16;
   // CLS: 256 bytes of eq2 in front of a table of up to 64 KB - one more 16-byte piece per thread
-  constexpr uint32_t kStagePieces = kStreamTabBytes / 16 / THREADS + (CLS ? 1 : 0);
+  constexpr uint32_t kStagePieces = BIG ? 1 : kStreamTabBytes / 16 / THREADS + (CLS ? 1 : 0);
   uint4 tv[kStagePieces];
+  if (BIG) {  // up to 155 KB: straight through, no register staging
+    for (uint32_t i = threadIdx.x; i < n16; i += THREADS) reinterpret_cast<uint4 *>(tab)[i] = tsrc[i];
+  }
 #pragma unroll
   for (uint32_t k = 0; k < kStagePieces; ++k) {
     const uint32_t i = k * THREADS + threadIdx.x;
-    tv[k] = i < n16 ? tsrc[i] : make_uint4(0, 0, 0, 0);
+    tv[k] = (!BIG && i < n16) ? tsrc[i] : make_uint4(0, 0, 0, 0);
   }
   const int32_t myRes = IDXD ? 0 : threadIdx.x < d.nStates ? d.result[threadIdx.x] : 0;
   BlockRegs<HALVES> A[CH], B[CH];
@@ -363,7 +427,7 @@ k_stream(DevDfa d, Batch io) {
 #pragma unroll
     for (uint32_t k = 0; k < kStagePieces; ++k) {
       const uint32_t i = k * THREADS + threadIdx.x;
-      if (i < (kStreamTabBytes + 1024) / 16) dst[i] = tv[k];
+      if (!BIG && i < (kStreamTabBytes + 1024) / 16) dst[i] = tv[k];
     }
     if (!CLS && threadIdx.x < 256) ldsRes[threadIdx.x] = myRes;
   }
@@ -419,19 +483,19 @@ k_stream(DevDfa d, Batch io) {
       uint4 piece[CH];
 #pragma unroll
       for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[4 * h + 0];
-      if constexpr (CLS) streamWalk16Cls<MODE, 0>(piece, s, b, mA, mB, firstAccept, init, tab);
+      if constexpr (CLS) streamWalk16Cls<MODE, 0, BIG>(piece, s, b, mA, mB, firstAccept, init, tab, d.clsRowBytes);
       else streamWalk16<MODE, 0>(piece, s, b, mA, mB, firstAccept, init);
 #pragma unroll
       for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[4 * h + 1];
-      if constexpr (CLS) streamWalk16Cls<MODE, 1>(piece, s, b, mA, mB, firstAccept, init, tab);
+      if constexpr (CLS) streamWalk16Cls<MODE, 1, BIG>(piece, s, b, mA, mB, firstAccept, init, tab, d.clsRowBytes);
       else streamWalk16<MODE, 1>(piece, s, b, mA, mB, firstAccept, init);
 #pragma unroll
       for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[4 * h + 2];
-      if constexpr (CLS) streamWalk16Cls<MODE, 2>(piece, s, b, mA, mB, firstAccept, init, tab);
+      if constexpr (CLS) streamWalk16Cls<MODE, 2, BIG>(piece, s, b, mA, mB, firstAccept, init, tab, d.clsRowBytes);
       else streamWalk16<MODE, 2>(piece, s, b, mA, mB, firstAccept, init);
 #pragma unroll
       for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[4 * h + 3];
-      if constexpr (CLS) streamWalk16Cls<MODE, 3>(piece, s, b, mA, mB, firstAccept, init, tab);
+      if constexpr (CLS) streamWalk16Cls<MODE, 3, BIG>(piece, s, b, mA, mB, firstAccept, init, tab, d.clsRowBytes);
       else streamWalk16<MODE, 3>(piece, s, b, mA, mB, firstAccept, init);
       const uint32_t off = r * BLK + h * 64;
       bool redo[CH];

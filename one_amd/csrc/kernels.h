@@ -27,7 +27,8 @@ struct DevDfa {
   // REDGPU_TAB_HOT_ROWS (dfa_image.h), else 0: hot states [hotLo, hotLo + nHot), the 64 KB
   // [hot index][byte] u8 table at table + hot8Off, hot index = s - hotLo + hotShift
   uint32_t hotLo, nHot, hot8Off, hotShift;
-  uint32_t clsOff, clsRowBytes, clsBytes;  // streaming form of a <= 64 KB class table, or 0
+  uint32_t clsOff, clsRowBytes, clsBytes;  // streaming form of the class table, or 0
+  uint32_t clsIndexForm;         // its entries are state indices (tables above 64 KB), not row offsets
   uint32_t earlyDeath;           // the visit model sees walks die within 16 bytes
   uint32_t tuned;                // hot rows ranked by observed visits
   uint32_t forgetful;            // the walk is mostly in the initial state (k_chunk.h)

@@ -1442,7 +1442,8 @@ static bool hotStreamEligible(const DevDfa &d) {
 
 // DFAs of more than 256 states with a class table of at most 64 KB: k_stream's class-table form
 static bool clsStreamEligible(const DevDfa &d) {
-  return d.clsOff != 0 && d.clsBytes <= kStreamTabBytes + 1024 && d.deadAbsorbing;
+  return d.clsOff != 0 && d.deadAbsorbing &&
+         d.clsBytes <= (d.clsIndexForm ? kStreamBigLds : kStreamTabBytes + 1024);
 }
 
 bool fastPathEligible(const DevDfa &d) {
@@ -1604,7 +1605,8 @@ hipError_t launchAdvance(const DevDfa &d, const Batch &b, uint32_t *state, const
     sb.state = state;
     sb.start = nullptr;
     sb.end = nullptr;
-    return launchStreamHot<kSmAdvance, kTabCls>(d, sb, cfg, stream);
+    return d.clsIndexForm ? launchStreamHot<kSmAdvance, kTabClsBig>(d, sb, cfg, stream)
+                          : launchStreamHot<kSmAdvance, kTabCls>(d, sb, cfg, stream);
   }
   if (!cfg.forceGeneric && hotStreamEligible(d) && !b.offsets && b.stride >= 64 &&
       b.stride % 64 == 0 && b.stride < (1ull << 31) &&
@@ -1724,11 +1726,11 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
     Batch sb = b;
     if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
     if (style == kStyLast) {
-      if (sb.start) { *kernelName = "k_stream<last,start,end,cls>"; e = launchStreamHot<kSmLastStartEnd, kTabCls>(d, sb, cfg, stream); }
-      else { *kernelName = "k_stream<last,end,cls>"; e = launchStreamHot<kSmLastEnd, kTabCls>(d, sb, cfg, stream); }
+      if (sb.start) { *kernelName = "k_stream<last,start,end,cls>"; e = d.clsIndexForm ? launchStreamHot<kSmLastStartEnd, kTabClsBig>(d, sb, cfg, stream) : launchStreamHot<kSmLastStartEnd, kTabCls>(d, sb, cfg, stream); }
+      else { *kernelName = "k_stream<last,end,cls>"; e = d.clsIndexForm ? launchStreamHot<kSmLastEnd, kTabClsBig>(d, sb, cfg, stream) : launchStreamHot<kSmLastEnd, kTabCls>(d, sb, cfg, stream); }
     } else {
-      if (sb.start) { *kernelName = "k_stream<full,start,cls>"; e = launchStreamHot<kSmFullStart, kTabCls>(d, sb, cfg, stream); }
-      else { *kernelName = "k_stream<full,cls>"; e = launchStreamHot<kSmFull, kTabCls>(d, sb, cfg, stream); }
+      if (sb.start) { *kernelName = "k_stream<full,start,cls>"; e = d.clsIndexForm ? launchStreamHot<kSmFullStart, kTabClsBig>(d, sb, cfg, stream) : launchStreamHot<kSmFullStart, kTabCls>(d, sb, cfg, stream); }
+      else { *kernelName = "k_stream<full,cls>"; e = d.clsIndexForm ? launchStreamHot<kSmFull, kTabClsBig>(d, sb, cfg, stream) : launchStreamHot<kSmFull, kTabCls>(d, sb, cfg, stream); }
     }
     if (e != hipSuccess) return e;
     if (lead) {
@@ -1803,7 +1805,8 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
   }
 
   // ... and for mid-size DFAs with a class table of at most 64 KB
-  const bool clsRaggedOk = !cfg.forceGeneric && !dying && clsStreamEligible(d) && b.offsets &&
+  const bool clsRaggedOk = !cfg.forceGeneric && !dying && clsStreamEligible(d) &&
+                           !d.clsIndexForm && b.offsets &&
                            (verb == kCheck || verb == kMatch) &&
                            (style == kStyLast || style == kStyFull) && !lead;
   if (clsRaggedOk) {

@@ -255,6 +255,7 @@ int uploadImage(SharedImage *im) {
   d.clsOff = img.clsOff;
   d.clsRowBytes = img.clsRowBytes;
   d.clsBytes = img.clsBytes;
+  d.clsIndexForm = img.clsIndexForm ? 1 : 0;
   d.tuned = img.tuned ? 1 : 0;
   d.forgetful = img.forgetful ? 1 : 0;
   d.startLeadWord = img.startLeadWord;

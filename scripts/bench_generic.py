@@ -75,3 +75,9 @@ exe_u3 = one_amd.Executable(load_dfa("uri_user"))
 exe_u3.tune(dd[: 64 << 14], stride=64, n=1 << 14)
 timeit(lambda: one_amd.match_batch(exe_u3, dd, 4, 0, stride=64, n=1 << 20), tt.size,
        "URI-USER (343 st) same, after tune [kind %d]" % exe_u3.info["table_kind"], it=5)
+# class table above 64 KB (1500 states x 40 classes = 120 KB): index-form streaming kernel vs generic
+blob_big = random_dfa(1500, 40, 5, accept_frac=0.1)
+for kw, label in (({}, "default"), ({"force_generic": True}, "k_generic")):
+    exe_b = one_amd.Executable(blob_big, **kw)
+    timeit(lambda: one_amd.match_batch(exe_b, d6, 4, 0, stride=L6, n=n6), n6 * L6,
+           "RND-1500x40 (120 KB class table) 2^18 x 1 KiB, %s" % label, it=3)

@@ -320,7 +320,8 @@ def test_hot_row_ragged_kernel_vs_oracle(case):
                                       cpu.batch("check", sty, 0, data, offsets=offsets, threads=8)[0])
 
 
-@pytest.mark.parametrize("case", ["uri_user", "rnd700x30", "rnd257x100_dead", "rnd1300x25"])
+@pytest.mark.parametrize("case", ["uri_user", "rnd700x30", "rnd257x100_dead", "rnd1300x25",
+                                  "rnd1500x40_big", "rnd900x80_big_dead"])
 def test_class_table_streaming_kernel_vs_oracle(case):
     """k_stream<.., cls>: fixed-stride lines over a DFA of more than 256 states whose class table
     (<= 64 KB) sits in LDS in row-offset form - two lookups per byte, no cold path.  Every mode,
@@ -330,13 +331,16 @@ def test_class_table_streaming_kernel_vs_oracle(case):
         mk = lambda n, L, seed: W.fixed_lines(n, L, seed, alphabet=True, plant=W.URI_USER_PLANT,
                                               plant_every=3, plant_at=L // 2 - 20)
     else:
+        # "_big": class table above 64 KB (120 / 144 KB) - the index form, one workgroup per CU
         n_st, n_cls = {"rnd700x30": (700, 30), "rnd257x100_dead": (258, 100),
-                       "rnd1300x25": (1300, 25)}[case]
+                       "rnd1300x25": (1300, 25), "rnd1500x40_big": (1500, 40),
+                       "rnd900x80_big_dead": (900, 80)}[case]
         blob = random_dfa(n_st, n_cls, 91, dead_frac=0.01 if case.endswith("dead") else 0.0,
                           accept_frac=0.15)
         mk = lambda n, L, seed: W.fixed_lines(n, L, seed, alphabet=False)
     exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
     assert exe.info["table_kind"] in (2, 3), exe.info
+    assert ("big" in case) == (exe.info["table_bytes"] > 65536 and exe.info["table_kind"] == 3)
     for n, L in ((3001, 64), (1500, 128), (700, 192), (130, 4096)):
         data = mk(n, L, 200 + L)
         for sty in (4, 5):
@@ -496,17 +500,17 @@ def test_tune_reranks_hot_rows_results_unchanged():
     # tuning a DFA whose fused table lives in LDS is a no-op that still validates its arguments
     small = one_amd.Executable(load_dfa("uri"))
     assert small.tune(sample, stride=L, n=n)["table_kind"] == 1
-    # a DFA of more than 256 states whose class table fits LDS but not the 64 KB streaming form
-    # (1500 states x 40 classes = 120 KB: generic kernel) moves to hot rows + streaming kernel
+    # a DFA of more than 256 states whose table fits LDS but has no streaming form of its own
+    # (280 states x 200 classes: more than 127 classes) moves to hot rows + streaming kernel
     # when the observed walk is practically all hot; a 343-state one (17 KB class table: its
     # own streaming form, k_stream cls) stays where it is
     mid = one_amd.Executable(load_dfa("uri_user"))
     assert mid.info["table_kind"] == 3 and mid.tune(held, stride=L, n=n)["table_kind"] == 3
     one_amd.match_batch(mid, held, 4, 0, stride=L, n=n)
     assert one_amd.last_kernel() == "k_stream<last,start,end,cls>"
-    bblob = random_dfa(1500, 40, 5, accept_frac=0.1)
+    bblob = random_dfa(280, 200, 5, accept_frac=0.1)
     big = one_amd.Executable(bblob)
-    assert big.info["table_kind"] == 3
+    assert big.info["table_kind"] == 2
     zeros = np.zeros(n * L, dtype=np.uint8)           # a walk that soon cycles through few states
     after_big = big.tune(zeros, stride=L, n=n)
     assert after_big["table_kind"] == 6, after_big

@@ -111,67 +111,85 @@ __device__ __forceinline__ void raggedWalk16(const uint4 (&piece)[2], uint32_t (
 // class-table form of the step (k_stream.h, TABK == kTabCls): row + 2 x class, ds_read_u16
 #define RGC_I_CHAIN(c) [s##c] "v"(s[c]), [k##c] "v"(cls[c]), [rem##c] "v"(rem[c])
 
-template <int MODE, int IDX>
-__device__ __forceinline__ void raggedStepCls(uint32_t (&s)[2], const uint32_t (&cls)[2],
+// the index form (tables above 64 KB) computes state x rowBytes + 2 x class first (RC_MAD, its
+// own statement) and enters the shared statement with that as the "class" operand and a plain
+// move in place of the add
+#define RGC_MOV(c) "v_mov_b32 %[a" #c "], %[k" #c "]\n\t"
+#define RGC_STEP(ADDR0, ADDR1)                                                                   \
+  if constexpr (MODE == kSmLastStartEnd) {                                                       \
+    asm volatile(ADDR0 ADDR1 RC_READ(0) RC_READ(1) RG_VALID(0) RG_VALID(1)                       \
+                 RG_CMPA(0) RG_CMPA(1) RG_CMPI(0) RG_CMPI(1) RG_ACC(0) RG_ACC(1)                 \
+                 RG_MEND(0) RG_MEND(1) RG_END(0) RG_END(1)                                       \
+                 RG_LEAVE(0) RG_LEAVE(1) RG_START(0) RG_START(1) RG_WAIT RG_HOLD(0) RG_HOLD(1)   \
+                 : RG_O_CHAIN(0), RG_O_CHAIN(1), RG_O_ACC(0), RG_O_ACC(1), RG_O_START(0),        \
+                   RG_O_START(1)                                                                 \
+                 : RGC_I_CHAIN(0), RGC_I_CHAIN(1), RG_I_ACC(0), RG_I_ACC(1), RG_I_START(0),      \
+                   RG_I_START(1), [T] "s"(T), [init] "s"(init), [idx] "n"(IDX)                   \
+                 : "memory", "scc");                                                             \
+  } else if constexpr (MODE == kSmLastEnd) {                                                     \
+    asm volatile(ADDR0 ADDR1 RC_READ(0) RC_READ(1) RG_VALID(0) RG_VALID(1)                       \
+                 RG_CMPA(0) RG_CMPA(1) "s_nop 0\n\t" RG_ACC(0) RG_ACC(1)                         \
+                 RG_MEND(0) RG_MEND(1) RG_END(0) RG_END(1) RG_WAIT RG_HOLD(0) RG_HOLD(1)         \
+                 : RG_O_CHAIN(0), RG_O_CHAIN(1), RG_O_ACC(0), RG_O_ACC(1)                        \
+                 : RGC_I_CHAIN(0), RGC_I_CHAIN(1), RG_I_ACC(0), RG_I_ACC(1), [T] "s"(T),         \
+                   [idx] "n"(IDX)                                                                \
+                 : "memory", "scc");                                                             \
+  } else if constexpr (MODE == kSmFullStart) {                                                   \
+    asm volatile(ADDR0 ADDR1 RC_READ(0) RC_READ(1) RG_VALID(0) RG_VALID(1)                       \
+                 RG_CMPI(0) RG_CMPI(1) "s_nop 0\n\t" RG_LEAVE(0) RG_LEAVE(1)                     \
+                 RG_START(0) RG_START(1) RG_WAIT RG_HOLD(0) RG_HOLD(1)                           \
+                 : RG_O_CHAIN(0), RG_O_CHAIN(1), RG_O_START(0), RG_O_START(1)                    \
+                 : RGC_I_CHAIN(0), RGC_I_CHAIN(1), RG_I_START(0), RG_I_START(1),                 \
+                   [init] "s"(init), [idx] "n"(IDX)                                              \
+                 : "memory", "scc");                                                             \
+  } else {                                                                                       \
+    asm volatile(ADDR0 ADDR1 RC_READ(0) RC_READ(1) RG_VALID(0) RG_VALID(1)                       \
+                 RG_WAIT "s_nop 0\n\t" RG_HOLD(0) RG_HOLD(1)                                     \
+                 : RG_O_CHAIN(0), RG_O_CHAIN(1)                                                  \
+                 : RGC_I_CHAIN(0), RGC_I_CHAIN(1), [idx] "n"(IDX)                                \
+                 : "memory");                                                                    \
+  }
+
+template <int MODE, int IDX, bool BIG>
+__device__ __forceinline__ void raggedStepCls(uint32_t (&s)[2], const uint32_t (&clsIn)[2],
                                               const uint32_t (&rem)[2], StreamBook (&b)[2],
                                               const uint64_t (&wasI)[2], uint64_t (&isI)[2],
                                               const uint64_t (&validPrev)[2],
-                                              uint64_t (&validNow)[2], uint32_t T, uint32_t init) {
+                                              uint64_t (&validNow)[2], uint32_t T, uint32_t init,
+                                              uint32_t rowb) {
   uint32_t a[2], t[2];
   uint64_t m[2], mr[2], l[2];
-  if constexpr (MODE == kSmLastStartEnd) {
-    asm volatile(RC_ADD(0) RC_ADD(1) RC_READ(0) RC_READ(1) RG_VALID(0) RG_VALID(1)
-                 RG_CMPA(0) RG_CMPA(1) RG_CMPI(0) RG_CMPI(1) RG_ACC(0) RG_ACC(1)
-                 RG_MEND(0) RG_MEND(1) RG_END(0) RG_END(1)
-                 RG_LEAVE(0) RG_LEAVE(1) RG_START(0) RG_START(1) RG_WAIT RG_HOLD(0) RG_HOLD(1)
-                 : RG_O_CHAIN(0), RG_O_CHAIN(1), RG_O_ACC(0), RG_O_ACC(1), RG_O_START(0),
-                   RG_O_START(1)
-                 : RGC_I_CHAIN(0), RGC_I_CHAIN(1), RG_I_ACC(0), RG_I_ACC(1), RG_I_START(0),
-                   RG_I_START(1), [T] "s"(T), [init] "s"(init), [idx] "n"(IDX)
-                 : "memory", "scc");
-  } else if constexpr (MODE == kSmLastEnd) {
-    asm volatile(RC_ADD(0) RC_ADD(1) RC_READ(0) RC_READ(1) RG_VALID(0) RG_VALID(1)
-                 RG_CMPA(0) RG_CMPA(1) "s_nop 0\n\t" RG_ACC(0) RG_ACC(1)
-                 RG_MEND(0) RG_MEND(1) RG_END(0) RG_END(1) RG_WAIT RG_HOLD(0) RG_HOLD(1)
-                 : RG_O_CHAIN(0), RG_O_CHAIN(1), RG_O_ACC(0), RG_O_ACC(1)
-                 : RGC_I_CHAIN(0), RGC_I_CHAIN(1), RG_I_ACC(0), RG_I_ACC(1), [T] "s"(T),
-                   [idx] "n"(IDX)
-                 : "memory", "scc");
-  } else if constexpr (MODE == kSmFullStart) {
-    asm volatile(RC_ADD(0) RC_ADD(1) RC_READ(0) RC_READ(1) RG_VALID(0) RG_VALID(1)
-                 RG_CMPI(0) RG_CMPI(1) "s_nop 0\n\t" RG_LEAVE(0) RG_LEAVE(1)
-                 RG_START(0) RG_START(1) RG_WAIT RG_HOLD(0) RG_HOLD(1)
-                 : RG_O_CHAIN(0), RG_O_CHAIN(1), RG_O_START(0), RG_O_START(1)
-                 : RGC_I_CHAIN(0), RGC_I_CHAIN(1), RG_I_START(0), RG_I_START(1),
-                   [init] "s"(init), [idx] "n"(IDX)
-                 : "memory", "scc");
+  uint32_t cls[2] = {clsIn[0], clsIn[1]};
+  if constexpr (BIG) {
+    asm volatile(RC_MAD(0) RC_MAD(1)
+                 : [a0] "=&v"(cls[0]), [a1] "=&v"(cls[1])
+                 : [s0] "v"(s[0]), [s1] "v"(s[1]), [k0] "v"(clsIn[0]), [k1] "v"(clsIn[1]),
+                   [rowb] "s"(rowb));
+    RGC_STEP(RGC_MOV(0), RGC_MOV(1))
   } else {
-    asm volatile(RC_ADD(0) RC_ADD(1) RC_READ(0) RC_READ(1) RG_VALID(0) RG_VALID(1)
-                 RG_WAIT "s_nop 0\n\t" RG_HOLD(0) RG_HOLD(1)
-                 : RG_O_CHAIN(0), RG_O_CHAIN(1)
-                 : RGC_I_CHAIN(0), RGC_I_CHAIN(1), [idx] "n"(IDX)
-                 : "memory");
+    RGC_STEP(RC_ADD(0), RC_ADD(1))
   }
   s[0] = t[0];
   s[1] = t[1];
 }
+#undef RGC_STEP
 
-template <int MODE, int Q>
+template <int MODE, int Q, bool BIG>
 __device__ __forceinline__ void raggedWalk16Cls(const uint4 (&piece)[2], uint32_t (&s)[2],
                                                 const uint32_t (&rem)[2], StreamBook (&b)[2],
                                                 uint64_t (&mA)[2], uint64_t (&mB)[2],
                                                 uint64_t (&vA)[2], uint64_t (&vB)[2], uint32_t T,
-                                                uint32_t init, const uint8_t *eq2) {
+                                                uint32_t init, const uint8_t *eq2, uint32_t rowb) {
   uint32_t cl[4][2];
 #define RGC_WORD(K, FIELD)                                                                   \
   _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                            \
     cl[k][0] = eq2[(piece[0].FIELD >> (8 * k)) & 0xffu];                                     \
     cl[k][1] = eq2[(piece[1].FIELD >> (8 * k)) & 0xffu];                                     \
   }                                                                                          \
-  raggedStepCls<MODE, 16 * Q + 4 * K + 0>(s, cl[0], rem, b, mA, mB, vA, vB, T, init);        \
-  raggedStepCls<MODE, 16 * Q + 4 * K + 1>(s, cl[1], rem, b, mB, mA, vB, vA, T, init);        \
-  raggedStepCls<MODE, 16 * Q + 4 * K + 2>(s, cl[2], rem, b, mA, mB, vA, vB, T, init);        \
-  raggedStepCls<MODE, 16 * Q + 4 * K + 3>(s, cl[3], rem, b, mB, mA, vB, vA, T, init);
+  raggedStepCls<MODE, 16 * Q + 4 * K + 0, BIG>(s, cl[0], rem, b, mA, mB, vA, vB, T, init, rowb);        \
+  raggedStepCls<MODE, 16 * Q + 4 * K + 1, BIG>(s, cl[1], rem, b, mB, mA, vB, vA, T, init, rowb);        \
+  raggedStepCls<MODE, 16 * Q + 4 * K + 2, BIG>(s, cl[2], rem, b, mA, mB, vA, vB, T, init, rowb);        \
+  raggedStepCls<MODE, 16 * Q + 4 * K + 3, BIG>(s, cl[3], rem, b, mB, mA, vB, vA, T, init, rowb);
   RGC_WORD(0, x) RGC_WORD(1, y) RGC_WORD(2, z) RGC_WORD(3, w)
 #undef RGC_WORD
 }
@@ -228,28 +246,33 @@ template <int MODE, int TABK = kTabFused>
 __global__ void __launch_bounds__(kStreamThreads)
 k_ragged(DevDfa d, Batch io) {
   constexpr bool HOT = TABK == kTabHot;
-  constexpr bool CLS = TABK == kTabCls;
+  constexpr bool BIG = TABK == kTabClsBig;  // class table above 64 KB, index form (k_stream.h)
+  constexpr bool CLS = TABK == kTabCls || BIG;
   constexpr bool IDXD = HOT || CLS;  // the walk's state values are not device state ids
   constexpr int CH = kStreamChains;
   constexpr int THREADS = kStreamThreads;
   constexpr bool kAcc = MODE == kSmLastStartEnd || MODE == kSmLastEnd;
   constexpr bool kStart = MODE == kSmLastStartEnd || MODE == kSmFullStart;
-  __shared__ __align__(16) uint8_t lds[kStreamTabBytes + 1024];  // table at LDS offset 0
+  constexpr uint32_t kLdsBytes = BIG ? kStreamBigLds : kStreamTabBytes + 1024;
+  __shared__ __align__(16) uint8_t lds[kLdsBytes];  // table at LDS offset 0
   uint8_t *tab = lds;
   int32_t *ldsRes = reinterpret_cast<int32_t *>(lds + kStreamTabBytes);
 
   // HOT: the walk runs in hot-index space (k_stream.h)
   const uint32_t init =
       HOT ? (d.init - d.hotLo < d.nHot ? d.init - d.hotLo + d.hotShift : 0x1ffu)
-          : CLS ? d.init * d.clsRowBytes : d.init;
+          : (CLS && !BIG) ? d.init * d.clsRowBytes : d.init;
   const uint32_t firstAccept = HOT ? d.firstAccept - d.hotLo + d.hotShift
-                                   : CLS ? d.firstAccept * d.clsRowBytes : d.firstAccept;
+                                   : (CLS && !BIG) ? d.firstAccept * d.clsRowBytes
+                                                   : d.firstAccept;
   auto toHot = [&](uint32_t st) -> uint32_t {
+    if (BIG) return st;
     if (CLS) return st * d.clsRowBytes;
     if (d.hotShift && st < d.nPureDead) return 0u;
     return st - d.hotLo < d.nHot ? st - d.hotLo + d.hotShift : 255u;
   };
   auto toGlobal = [&](uint32_t idx) -> uint32_t {
+    if (BIG) return idx;
     if (CLS) return idx / d.clsRowBytes;
     return (d.hotShift && idx == 0) ? 0u : d.hotLo + idx - d.hotShift;
   };
@@ -260,19 +283,22 @@ k_ragged(DevDfa d, Batch io) {
     const uint4 *src =
         reinterpret_cast<const uint4 *>(d.table + (HOT ? d.hot8Off : CLS ? d.clsOff : 0u));
     const uint32_t n16 = HOT ? kStreamTabBytes / 16 : CLS ? d.clsBytes / 16 : d.tableBytes / 16;
-    constexpr uint32_t kStagePieces = kStreamTabBytes / 16 / THREADS + (CLS ? 1 : 0);
+    constexpr uint32_t kStagePieces = BIG ? 1 : kStreamTabBytes / 16 / THREADS + (CLS ? 1 : 0);
     uint4 v[kStagePieces];
+    if (BIG) {
+      for (uint32_t i = threadIdx.x; i < n16; i += THREADS) reinterpret_cast<uint4 *>(tab)[i] = src[i];
+    }
 #pragma unroll
     for (uint32_t k = 0; k < kStagePieces; ++k) {
       const uint32_t i = k * THREADS + threadIdx.x;
-      v[k] = i < n16 ? src[i] : make_uint4(0, 0, 0, 0);
+      v[k] = (!BIG && i < n16) ? src[i] : make_uint4(0, 0, 0, 0);
     }
     const int32_t myRes = IDXD ? 0 : threadIdx.x < d.nStates ? d.result[threadIdx.x] : 0;
     uint4 *dst = reinterpret_cast<uint4 *>(tab);
 #pragma unroll
     for (uint32_t k = 0; k < kStagePieces; ++k) {
       const uint32_t i = k * THREADS + threadIdx.x;
-      if (i < (kStreamTabBytes + 1024) / 16) dst[i] = v[k];
+      if (!BIG && i < (kStreamTabBytes + 1024) / 16) dst[i] = v[k];
     }
     if (!CLS && threadIdx.x < 256) ldsRes[threadIdx.x] = myRes;
   }
@@ -351,19 +377,19 @@ k_ragged(DevDfa d, Batch io) {
       uint4 piece[CH];
 #pragma unroll
       for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[0];
-      if constexpr (CLS) raggedWalk16Cls<MODE, 0>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init, tab);
+      if constexpr (CLS) raggedWalk16Cls<MODE, 0, BIG>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init, tab, d.clsRowBytes);
       else raggedWalk16<MODE, 0>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
 #pragma unroll
       for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[1];
-      if constexpr (CLS) raggedWalk16Cls<MODE, 1>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init, tab);
+      if constexpr (CLS) raggedWalk16Cls<MODE, 1, BIG>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init, tab, d.clsRowBytes);
       else raggedWalk16<MODE, 1>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
 #pragma unroll
       for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[2];
-      if constexpr (CLS) raggedWalk16Cls<MODE, 2>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init, tab);
+      if constexpr (CLS) raggedWalk16Cls<MODE, 2, BIG>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init, tab, d.clsRowBytes);
       else raggedWalk16<MODE, 2>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
 #pragma unroll
       for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[3];
-      if constexpr (CLS) raggedWalk16Cls<MODE, 3>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init, tab);
+      if constexpr (CLS) raggedWalk16Cls<MODE, 3, BIG>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init, tab, d.clsRowBytes);
       else raggedWalk16<MODE, 3>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
       // fold (as k_stream); the state after the block's 64th byte counts only if that byte
       // was part of the line (rem == 64) - vA holds "step 63 was valid" for exactly that

@@ -575,6 +575,7 @@ k_stream(DevDfa d, Batch io) {
 
   if (!EARLY) issue(A);
   for (uint64_t q = 0; q < Q; q += 2) {
+    if (q == 0 && (io.exp & 1u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     issue(B);
     walkBlock(A);
     issue(A);
@@ -621,12 +622,18 @@ hipError_t launchStreamTT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
   const uint64_t tiles = (b.n + linesPerTile - 1) / linesPerTile;
   // one workgroup per CU: two (32 chains per CU) measured 26.0 us against 24.7 us on configs[1]
   const uint64_t blocks = tiles < uint64_t(cfg.numCUs) ? tiles : uint64_t(cfg.numCUs);
+  static const uint32_t exp = [] {
+    const char *e = getenv("REDGPU_EXP");
+    return e ? uint32_t(strtoul(e, nullptr, 0)) : 0u;
+  }();
+  Batch eb = b;
+  eb.exp = exp;
   if (b.stride % 128 == 0)
     hipLaunchKernelGGL((k_stream<MODE, 2, THREADS>), dim3(uint32_t(blocks)), dim3(THREADS), 0,
-                       stream, d, b);
+                       stream, d, eb);
   else
     hipLaunchKernelGGL((k_stream<MODE, 1, THREADS>), dim3(uint32_t(blocks)), dim3(THREADS), 0,
-                       stream, d, b);
+                       stream, d, eb);
   return hipGetLastError();
 }
 

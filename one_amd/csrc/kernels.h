@@ -50,6 +50,7 @@ struct Batch {
   uint32_t *state = nullptr; // advance only: per-line StatefulMatcher state, in/out
   const uint32_t *perm = nullptr; // k_ragged only: slot -> line (lines bucketed by length)
   const uint8_t *pad = nullptr;   // k_ragged only: copy of the buffer's last 128 bytes + zeros
+  uint32_t exp = 0;               // k_stream only: REDGPU_EXP experiment bits (tuning knob)
 };
 
 struct LaunchCfg {

@@ -1805,21 +1805,20 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
   }
 
   // ... and for mid-size DFAs with a class table of at most 64 KB
-  const bool clsRaggedOk = !cfg.forceGeneric && !dying && clsStreamEligible(d) &&
-                           !d.clsIndexForm && b.offsets &&
+  const bool clsRaggedOk = !cfg.forceGeneric && !dying && clsStreamEligible(d) && b.offsets &&
                            (verb == kCheck || verb == kMatch) &&
                            (style == kStyLast || style == kStyFull) && !lead;
   if (clsRaggedOk) {
     Batch sb = b;
     if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
     if (style == kStyLast) {
-      if (sb.start) { *kernelName = "k_ragged<last,start,end,cls>"; return launchRaggedT<kSmLastStartEnd, kTabCls>(d, sb, cfg, stream); }
+      if (sb.start) { *kernelName = "k_ragged<last,start,end,cls>"; return d.clsIndexForm ? launchRaggedT<kSmLastStartEnd, kTabClsBig>(d, sb, cfg, stream) : launchRaggedT<kSmLastStartEnd, kTabCls>(d, sb, cfg, stream); }
       *kernelName = "k_ragged<last,end,cls>";
-      return launchRaggedT<kSmLastEnd, kTabCls>(d, sb, cfg, stream);
+      return d.clsIndexForm ? launchRaggedT<kSmLastEnd, kTabClsBig>(d, sb, cfg, stream) : launchRaggedT<kSmLastEnd, kTabCls>(d, sb, cfg, stream);
     }
-    if (sb.start) { *kernelName = "k_ragged<full,start,cls>"; return launchRaggedT<kSmFullStart, kTabCls>(d, sb, cfg, stream); }
+    if (sb.start) { *kernelName = "k_ragged<full,start,cls>"; return d.clsIndexForm ? launchRaggedT<kSmFullStart, kTabClsBig>(d, sb, cfg, stream) : launchRaggedT<kSmFullStart, kTabCls>(d, sb, cfg, stream); }
     *kernelName = "k_ragged<full,cls>";
-    return launchRaggedT<kSmFull, kTabCls>(d, sb, cfg, stream);
+    return d.clsIndexForm ? launchRaggedT<kSmFull, kTabClsBig>(d, sb, cfg, stream) : launchRaggedT<kSmFull, kTabCls>(d, sb, cfg, stream);
   }
 
   *kernelName = "k_generic";

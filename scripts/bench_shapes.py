@@ -7,10 +7,18 @@ blob = open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "df
 blob = blob or open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "dfas", "syn256.reda"), "rb").read()
 exe = one_amd.Executable(blob)
 shapes = [(1 << 20, 64), (1 << 24, 64), (1 << 22, 128), (1 << 22, 256), (1 << 18, 4096), (1 << 21, 4096), (1 << 14, 65536)]
+if os.environ.get("SHAPES"):  # e.g. SHAPES=1048576x64,2097152x4096
+    shapes = [tuple(int(v) for v in sh.split("x")) for sh in os.environ["SHAPES"].split(",")]
+# TEXT=1: bytes from the 47-character alphabet of the text workloads instead of uniform bytes
+alpha = torch.tensor(list(b"abcdefghijklmnopqrstuvwxyz0123456789 ./:-_=&?%"), dtype=torch.uint8, device="cuda")
+def make(total):
+    if os.environ.get("TEXT"):
+        return alpha[torch.randint(0, alpha.numel(), (total,), device="cuda")]
+    return torch.randint(0, 256, (total,), dtype=torch.uint8, device="cuda")
 for n, L in shapes:
     total = n * L
     nb = max(2, min(6, (3 << 30) // total))
-    bufs = [torch.randint(0, 256, (total,), dtype=torch.uint8, device="cuda") for _ in range(nb)]
+    bufs = [make(total) for _ in range(nb)]
     res = torch.empty(n, dtype=torch.int32, device="cuda")
     st = torch.empty(n, dtype=torch.int64, device="cuda")
     en = torch.empty(n, dtype=torch.int64, device="cuda")

@@ -373,7 +373,7 @@ def test_class_table_streaming_kernel_vs_oracle(case):
         assert np.array_equal(gstate, state)
 
 
-@pytest.mark.parametrize("case", ["uri_user", "rnd700x30", "rnd257x100_dead"])
+@pytest.mark.parametrize("case", ["uri_user", "rnd700x30", "rnd257x100_dead", "rnd1500x40_big"])
 def test_class_table_ragged_kernel_vs_oracle(case):
     """k_ragged<.., cls>: ragged lines over a mid-size DFA (class table <= 64 KB in LDS): every
     mode, empty lines, lines ending at the end of the buffer, long lines, with and without the
@@ -382,7 +382,8 @@ def test_class_table_ragged_kernel_vs_oracle(case):
     if case == "uri_user":
         blob, gen = load_dfa("uri_user"), W.alphabet_bytes
     else:
-        n_st, n_cls = {"rnd700x30": (700, 30), "rnd257x100_dead": (258, 100)}[case]
+        n_st, n_cls = {"rnd700x30": (700, 30), "rnd257x100_dead": (258, 100),
+                       "rnd1500x40_big": (1500, 40)}[case]
         blob = random_dfa(n_st, n_cls, 92, dead_frac=0.01 if case.endswith("dead") else 0.0,
                           accept_frac=0.15)
         gen = W.random_bytes

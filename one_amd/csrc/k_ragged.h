@@ -11,8 +11,8 @@
 //    "left the initial state" event (is-initial == was-initial) and re-recording it as the
 //    last accepting state is harmless; only the END position needs the mask of the previous
 //    step's validity.  8 VALU + 2 SALU per byte per line.
-//  * a wave walks as many blocks as its longest line needs (wave-uniform trip count from a
-//    cross-lane max); finished lanes re-read their last block (L1/L2 hits).
+//  * a lane whose line ends takes the next line of its workgroup's range at the next block
+//    boundary (see k_ragged below): no lane waits for the longest line of its wave.
 //  * lines start at arbitrary byte offsets: 16-byte loads at unaligned addresses (the memory
 //    pipeline splits them).  Block reads run up to 63 bytes past a line's end: a block that
 //    would reach past the end of the input buffer is read from `pad` instead - a 192-byte
@@ -194,13 +194,11 @@ __device__ __forceinline__ void raggedWalk16Cls(const uint4 (&piece)[2], uint32_
 #undef RGC_WORD
 }
 
-__device__ __forceinline__ uint32_t waveMaxU32(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    const uint32_t other = uint32_t(__shfl_xor(int(v), o, 64));
-    v = other > v ? other : v;
-  }
-  return uint32_t(__builtin_amdgcn_readfirstlane(int(v)));
+// a wave-uniform 64-bit value the compiler must keep in SGPRs (it feeds "s" asm operands)
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+  const uint32_t lo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v))));
+  const uint32_t hi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v >> 32))));
+  return (uint64_t(hi) << 32) | lo;
 }
 
 // HOT (REDGPU_TAB_HOT_ROWS DFAs; see k_stream.h): the lanes found in the sink after a 64-byte
@@ -242,23 +240,38 @@ __device__ __noinline__ SlowBook slowRagged(const DevDfa &d, const uint8_t *tab8
   return SlowBook{st, accS, endv, startv};
 }
 
+// =========================================================================================
+// k_ragged<MODE, TABK>: the ragged walk with the lanes kept busy.  The first form gave a lane one
+// line per tile and ran the wave for as many blocks as its longest line needed; here a lane whose
+// line ends takes the next line of the workgroup's range at the next block boundary, so a lane
+// idles only for the rest of its line's last block (uniform 32-256 B lines: 82 % of the steps are
+// valid against 56 %; geometric lengths the same 82 % against ~25 %, with no sorting pre-pass).
+//  * the workgroup owns the contiguous lines [n w / G, n (w + 1) / G); a cursor in LDS hands them
+//    out in input order, one wave-aggregated ds_add per block boundary (lanes of a wave hold
+//    neighbouring lines: reads and result stores stay local);
+//  * every lane holds its current line and the NEXT one (index, offset, length); the line after
+//    that is claimed, and its offsets requested, at the top of the block in which the current
+//    line ends - a whole block's walk ahead of the first use, unconditionally (lanes that claim
+//    nothing re-read offsets[0..1]) so the compiler's vmcnt counts stay exact;
+//  * an empty line takes one block slot with no valid step.
+// =========================================================================================
 template <int MODE, int TABK = kTabFused>
 __global__ void __launch_bounds__(kStreamThreads)
 k_ragged(DevDfa d, Batch io) {
   constexpr bool HOT = TABK == kTabHot;
-  constexpr bool BIG = TABK == kTabClsBig;  // class table above 64 KB, index form (k_stream.h)
+  constexpr bool BIG = TABK == kTabClsBig;
   constexpr bool CLS = TABK == kTabCls || BIG;
-  constexpr bool IDXD = HOT || CLS;  // the walk's state values are not device state ids
+  constexpr bool IDXD = HOT || CLS;
   constexpr int CH = kStreamChains;
   constexpr int THREADS = kStreamThreads;
   constexpr bool kAcc = MODE == kSmLastStartEnd || MODE == kSmLastEnd;
   constexpr bool kStart = MODE == kSmLastStartEnd || MODE == kSmFullStart;
   constexpr uint32_t kLdsBytes = BIG ? kStreamBigLds : kStreamTabBytes + 1024;
   __shared__ __align__(16) uint8_t lds[kLdsBytes];  // table at LDS offset 0
+  __shared__ uint32_t cursor;                       // lines of this workgroup's range handed out
   uint8_t *tab = lds;
   int32_t *ldsRes = reinterpret_cast<int32_t *>(lds + kStreamTabBytes);
 
-  // HOT: the walk runs in hot-index space (k_stream.h)
   const uint32_t init =
       HOT ? (d.init - d.hotLo < d.nHot ? d.init - d.hotLo + d.hotShift : 0x1ffu)
           : (CLS && !BIG) ? d.init * d.clsRowBytes : d.init;
@@ -276,9 +289,6 @@ k_ragged(DevDfa d, Batch io) {
     if (CLS) return idx / d.clsRowBytes;
     return (d.hotShift && idx == 0) ? 0u : d.hotLo + idx - d.hotShift;
   };
-  const uint64_t linesPerTile = uint64_t(THREADS) * CH;
-  const uint64_t nTiles = (io.n + linesPerTile - 1) / linesPerTile;
-  if (blockIdx.x >= nTiles) return;
   {
     const uint4 *src =
         reinterpret_cast<const uint4 *>(d.table + (HOT ? d.hot8Off : CLS ? d.clsOff : 0u));
@@ -301,173 +311,291 @@ k_ragged(DevDfa d, Batch io) {
       if (!BIG && i < (kStreamTabBytes + 1024) / 16) dst[i] = v[k];
     }
     if (!CLS && threadIdx.x < 256) ldsRes[threadIdx.x] = myRes;
+    if (threadIdx.x == 0) cursor = 0;
   }
   asm volatile("" : : "v"(tab) : "memory");  // the table is read from inline asm: see k_stream.h
   __syncthreads();
 
   const uint64_t total = io.offsets[io.n];
   const uint64_t padStart = total >= 128 ? total - 128 : 0;  // pad[] = data[padStart, total) + 0s
-  // the bucketing pass's verdict sits right behind the permutation
-  const bool usePerm = io.perm && io.perm[io.n] != 0;
   const int32_t initResult = IDXD ? (d.init >= d.firstAccept ? d.result[d.init] : 0)
                                  : (init >= firstAccept ? ldsRes[init] : 0);
+  // this workgroup's lines: the contiguous range [lo, lo + range).  (Handing them out longest
+  // first through the bucketing pass's permutation - so that a long line cannot start last -
+  // measured slower at every shape: 591 against 706 GB/s on geometric lengths.)
+  const uint64_t lo = io.n * blockIdx.x / gridDim.x;
+  const uint32_t range = uint32_t(io.n * (blockIdx.x + 1) / gridDim.x - lo);
+  const uint32_t lane = threadIdx.x & 63u;
 
-  for (uint64_t tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
-    uint64_t lineOff[CH];
-    uint32_t len[CH], lastBlk[CH];
-    uint64_t ln[CH];
-    bool mine[CH];
-    uint32_t blocksWanted = 0;
+  // current line, next line, and the claim in flight (valid for the lanes that made it)
+  bool have[CH], nHave[CH], dry[CH];
+  uint32_t ln[CH], len[CH], done[CH], nLn[CH], nLen[CH];
+  uint64_t lineOff[CH], nOff[CH];
+  uint32_t tLn[CH];
+  uint64_t tO[CH], tE[CH];
+  bool tHave[CH];
+
+  // wave-aggregated claim of one line for every (lane, chain) with want[c]; requests its offsets
+  auto claim = [&](const bool (&want)[CH]) {
+    uint64_t need[CH];
+    uint32_t k = 0, before[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      ln[c] = tile * linesPerTile + uint64_t(c) * THREADS + threadIdx.x;
-      uint64_t o = 0, e = 0;
-      mine[c] = false;
-      if (ln[c] < io.n) {
-        if (usePerm) ln[c] = io.perm[ln[c]];  // lines bucketed by length: see launchRaggedT
-        o = io.offsets[ln[c]];
-        e = io.offsets[ln[c] + 1];
-        mine[c] = true;
-      }
-      if (!mine[c]) { o = 0; e = 0; }  // idle lane: reads the buffer's first block, stores nothing
-      lineOff[c] = o;
-      // Batch::stride doubles as "trailing delimiter bytes per line" for ragged lines
-      len[c] = e - o >= io.stride ? uint32_t(e - o - io.stride) : 0u;
-      const uint32_t nb = (len[c] + 63u) >> 6;
-      lastBlk[c] = nb ? nb - 1 : 0;
-      blocksWanted = nb > blocksWanted ? nb : blocksWanted;
+      need[c] = __builtin_amdgcn_ballot_w64(want[c]);
+      before[c] = k;
+      k += uint32_t(__builtin_popcountll(need[c]));
     }
-    const uint32_t R = waveMaxU32(blocksWanted);  // this WAVE's trip count
-
-    uint32_t s[CH], accS[CH], endv[CH], startv[CH];
-    uint32_t g[CH];  // HOT: global id of the lane's state while it is outside the hot set
-    uint64_t mA[CH], mB[CH], vA[CH], vB[CH];
+    uint32_t base = 0;
+    if (k) {
+      if (lane == 0) base = atomicAdd(&cursor, k);
+      base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+    }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      s[c] = init; accS[c] = 0; endv[c] = 0; startv[c] = 0;
-      mA[c] = ~0ull; mB[c] = ~0ull; vA[c] = ~0ull; vB[c] = ~0ull;
-      g[c] = kNoState;
-      if (HOT && init == 0x1ffu) { s[c] = 255u; g[c] = d.init; }
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(need[c] >> 32),
+                                __builtin_amdgcn_mbcnt_lo(uint32_t(need[c]), 0u));
+      const uint32_t slot = base + before[c] + rank;
+      tHave[c] = want[c] && slot < range;
+      if (want[c] && !tHave[c]) dry[c] = true;
+      // unconditional requests (lanes that claimed nothing re-read entry 0)
+      const uint64_t at = tHave[c] ? lo + slot : 0;
+      tLn[c] = uint32_t(at);
+      tO[c] = io.offsets[at];
+      tE[c] = io.offsets[at + 1];
+    }
+  };
+  auto lengthOf = [&](uint64_t o, uint64_t e) -> uint32_t {
+    // Batch::stride doubles as "trailing delimiter bytes per line" for ragged lines
+    return e - o >= io.stride ? uint32_t(e - o - io.stride) : 0u;
+  };
+
+  uint32_t s[CH], accS[CH], endv[CH], startv[CH];
+  uint32_t g[CH];  // HOT: global id of the lane's state while it is outside the hot set
+  uint64_t mA[CH], mB[CH], vA[CH], vB[CH];
+  auto freshLine = [&](int c) {
+    s[c] = init; accS[c] = 0; endv[c] = 0; startv[c] = 0; g[c] = kNoState;
+    if (HOT && init == 0x1ffu) { s[c] = 255u; g[c] = d.init; }
+  };
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    dry[c] = false;
+    mA[c] = ~0ull; mB[c] = ~0ull; vA[c] = ~0ull; vB[c] = ~0ull;
+    done[c] = 0;
+    freshLine(c);
+  }
+  {
+    const bool all[CH] = {true, true};
+    claim(all);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      have[c] = tHave[c]; ln[c] = tLn[c]; lineOff[c] = have[c] ? tO[c] : 0;
+      len[c] = have[c] ? lengthOf(tO[c], tE[c]) : 0;
+    }
+    claim(all);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      nHave[c] = tHave[c]; nLn[c] = tLn[c]; nOff[c] = tO[c]; nLen[c] = lengthOf(tO[c], tE[c]);
+    }
+  }
+
+  // (Tried and dropped: reading ALIGNED 64-byte sectors and cutting the walk's window out of two
+  // of them in registers - a 4-stage barrel shift + v_alignbyte, ~95 VALU per window.  It removes
+  // the re-fetching of cache lines that unaligned blocks cause (TCC misses x 128 B = 3.3 x the
+  // input on 32-256 B lines) but this kernel is bound by VALU issue and step latency, not by
+  // memory: 2.21 against 2.73 TB/s on 256-byte lines, 1.42 against 1.54 TB/s on 32-256 B.)
+  BlockRegs<1> A[CH], B[CH];
+  auto blockPtr = [&](uint64_t bo) -> const uint8_t * {
+    return bo + 64 <= total ? io.data + bo : io.pad + (bo - padStart);
+  };
+  auto issueAt = [&](BlockRegs<1> (&blk)[CH], const uint64_t (&bo)[CH]) {
+    const uint8_t *src[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) src[c] = blockPtr(bo[c]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c) blk[c].p[k] = *reinterpret_cast<const uint4 *>(src[c] + 16 * k);
+    }
+  };
+
+  // one block of every lane's current line: X holds it, Y receives the block after it
+  auto turn = [&](const BlockRegs<1> (&X)[CH], BlockRegs<1> (&Y)[CH]) {
+    bool ends[CH];
+    {
+      uint64_t follow[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        ends[c] = !have[c] || done[c] + 64u >= len[c];
+        follow[c] = ends[c] ? (nHave[c] ? nOff[c] : 0) : lineOff[c] + done[c] + 64u;
+      }
+      issueAt(Y, follow);
+    }
+    {
+      bool want[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) want[c] = ends[c] && !dry[c];
+      claim(want);
+    }
+    // loop-carried lane masks: pinned to SGPRs where the asm steps take them
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      mA[c] = uniform64(mA[c]);
+      vA[c] = uniform64(vA[c]);
     }
 
-    BlockRegs<1> A[CH], B[CH];
-    auto issue = [&](BlockRegs<1> (&blk)[CH], uint32_t r) {
+    uint32_t rem[CH];
+    StreamBook b[CH];
+    uint32_t s0[CH];  // HOT: the block's entry state (hot index), for the re-walk
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+    for (int c = 0; c < CH; ++c) {
+      const uint32_t left = have[c] ? len[c] - done[c] : 0u;
+      rem[c] = left > 64u ? 64u : left;
+      b[c].acc = IDXD ? 0u : accS[c]; b[c].end = 0; b[c].start = 0;
+      s0[c] = s[c];
+    }
+    uint4 piece[CH];
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          const uint32_t rr = r < lastBlk[c] ? r : lastBlk[c];
-          const uint64_t bo = lineOff[c] + uint64_t(rr) * 64;
-          const uint8_t *src = bo + 64 <= total ? io.data + bo : io.pad + (bo - padStart);
-          blk[c].p[k] = *reinterpret_cast<const uint4 *>(src + 16 * k);
-        }
-      }
-    };
-    auto walk = [&](const BlockRegs<1> (&blk)[CH], uint32_t r) {
-      uint32_t rem[CH];
-      StreamBook b[CH];
-      uint32_t s0[CH];  // HOT: the block's entry state (hot index), for the re-walk
+    for (int c = 0; c < CH; ++c) piece[c] = X[c].p[0];
+    if constexpr (CLS) raggedWalk16Cls<MODE, 0, BIG>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init, tab, d.clsRowBytes);
+    else raggedWalk16<MODE, 0>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
 #pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        const uint32_t done = r * 64;
-        rem[c] = len[c] > done ? (len[c] - done > 64 ? 64 : len[c] - done) : 0;
-        b[c].acc = IDXD ? 0u : accS[c]; b[c].end = 0; b[c].start = 0;
-        s0[c] = s[c];
-      }
-      uint4 piece[CH];
+    for (int c = 0; c < CH; ++c) piece[c] = X[c].p[1];
+    if constexpr (CLS) raggedWalk16Cls<MODE, 1, BIG>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init, tab, d.clsRowBytes);
+    else raggedWalk16<MODE, 1>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
 #pragma unroll
-      for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[0];
-      if constexpr (CLS) raggedWalk16Cls<MODE, 0, BIG>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init, tab, d.clsRowBytes);
-      else raggedWalk16<MODE, 0>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
+    for (int c = 0; c < CH; ++c) piece[c] = X[c].p[2];
+    if constexpr (CLS) raggedWalk16Cls<MODE, 2, BIG>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init, tab, d.clsRowBytes);
+    else raggedWalk16<MODE, 2>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
 #pragma unroll
-      for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[1];
-      if constexpr (CLS) raggedWalk16Cls<MODE, 1, BIG>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init, tab, d.clsRowBytes);
-      else raggedWalk16<MODE, 1>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
+    for (int c = 0; c < CH; ++c) piece[c] = X[c].p[3];
+    if constexpr (CLS) raggedWalk16Cls<MODE, 3, BIG>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init, tab, d.clsRowBytes);
+    else raggedWalk16<MODE, 3>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
+
+    // fold (as k_ragged), with the block's offset in the line per lane
+    bool redo[CH];
 #pragma unroll
-      for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[2];
-      if constexpr (CLS) raggedWalk16Cls<MODE, 2, BIG>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init, tab, d.clsRowBytes);
-      else raggedWalk16<MODE, 2>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
-#pragma unroll
-      for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[3];
-      if constexpr (CLS) raggedWalk16Cls<MODE, 3, BIG>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init, tab, d.clsRowBytes);
-      else raggedWalk16<MODE, 3>(piece, s, rem, b, mA, mB, vA, vB, firstAccept, init);
-      // fold (as k_stream); the state after the block's 64th byte counts only if that byte
-      // was part of the line (rem == 64) - vA holds "step 63 was valid" for exactly that
-      const uint32_t off = r * 64;
-      bool redo[CH];
-#pragma unroll
-      for (int c = 0; c < CH; ++c) redo[c] = HOT && rem[c] != 0 && s[c] == 255u;
-      if (HOT && __builtin_amdgcn_ballot_w64(redo[0] || redo[CH - 1])) {
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          if (redo[c]) {
-            const uint64_t bo = lineOff[c] + uint64_t(off);
-            const uint8_t *src = bo + 64 <= total ? io.data + bo : io.pad + (bo - padStart);
-            const SlowBook o = slowRagged<MODE>(
-                d, tab, src, off, rem[c],
-                SlowBook{g[c] != kNoState ? g[c] : toGlobal(s0[c]), accS[c], endv[c], startv[c]});
-            accS[c] = o.accS; endv[c] = o.endv; startv[c] = o.startv;
-            s[c] = toHot(o.st);
-            g[c] = s[c] != 255u ? kNoState : o.st;
-          }
-        }
-      }
+    for (int c = 0; c < CH; ++c) redo[c] = HOT && rem[c] != 0 && s[c] == 255u;
+    if (HOT && __builtin_amdgcn_ballot_w64(redo[0] || redo[CH - 1])) {
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
-        if (HOT && redo[c]) continue;
-        const bool full = rem[c] == 64;
-        if (kAcc && !IDXD) {
-          accS[c] = b[c].acc;
-          endv[c] = b[c].end ? off + b[c].end : endv[c];
-          if (full && s[c] >= firstAccept) { accS[c] = s[c]; endv[c] = off + 64; }
+        if (redo[c]) {
+          const SlowBook o = slowRagged<MODE>(
+              d, tab, blockPtr(lineOff[c] + done[c]), done[c], rem[c],
+              SlowBook{g[c] != kNoState ? g[c] : toGlobal(s0[c]), accS[c], endv[c], startv[c]});
+          accS[c] = o.accS; endv[c] = o.endv; startv[c] = o.startv;
+          s[c] = toHot(o.st);
+          g[c] = s[c] != 255u ? kNoState : o.st;
         }
-        if (kAcc && IDXD) {
-          if (b[c].end) { accS[c] = toGlobal(b[c].acc); endv[c] = off + b[c].end; }
-          if (full && s[c] >= firstAccept && (CLS || s[c] != 255u)) {
-            accS[c] = toGlobal(s[c]);
-            endv[c] = off + 64;
-          }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (HOT && redo[c]) continue;
+      const uint32_t off = done[c];
+      const bool full = rem[c] == 64;
+      if (kAcc && !IDXD) {
+        accS[c] = b[c].acc;
+        endv[c] = b[c].end ? off + b[c].end : endv[c];
+        if (full && s[c] >= firstAccept) { accS[c] = s[c]; endv[c] = off + 64; }
+      }
+      if (kAcc && IDXD) {
+        if (b[c].end) { accS[c] = toGlobal(b[c].acc); endv[c] = off + b[c].end; }
+        if (full && s[c] >= firstAccept && (CLS || s[c] != 255u)) {
+          accS[c] = toGlobal(s[c]);
+          endv[c] = off + 64;
         }
+      }
+      if (kStart) {
+        startv[c] = b[c].start ? off + b[c].start - 1 : startv[c];
+        const bool wasInit63 = (mA[c] >> lane) & 1;
+        if (full && wasInit63 && s[c] != init) startv[c] = off + 63;
+      }
+    }
+
+    // The claimed lines' offsets (requested at the top of the turn) are taken BEFORE this turn's
+    // results are stored: vmcnt counts stores too, and conditional ones cannot be counted
+    // exactly, so a wait placed after them becomes vmcnt(0) and sits out their acknowledgements
+    // (+1.5-2 us per turn whenever some lane of the wave finishes a line, i.e. on every turn of
+    // mixed-length lines).
+    uint64_t pOff[CH];
+    uint32_t pLen[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      // (the empty asm keeps the compiler from hoisting this wait into the walk above)
+      asm volatile("" : "+v"(tO[c]), "+v"(tE[c]) : : "memory");
+      pOff[c] = tO[c];
+      pLen[c] = lengthOf(tO[c], tE[c]);
+      asm volatile("" : "+v"(pOff[c]), "+v"(pLen[c]) : : "memory");
+    }
+
+    // lines that ended in this block report; their lanes move on to the next line
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      {
+        // Every lane stores on every turn - the ones with nothing to report into a dummy slot
+        // behind the tail pad: stores under a branch are vm operations the compiler cannot
+        // count, and the next turn's waits for its input block degrade to vmcnt(0).
+        const bool report = have[c] && ends[c];
+        int32_t rr;
+        uint32_t en;
+        uint32_t st = startv[c];
+        const uint32_t accAt = report && endv[c] ? accS[c] : 0u;
+        if (len[c] == 0) {
+          rr = initResult;  // no byte walked: the start state's own result, positions 0
+          en = 0;
+          st = 0;
+        } else if (kAcc) {
+          rr = IDXD ? d.result[accAt] : ldsRes[accAt];
+          rr = endv[c] ? rr : 0;
+          en = endv[c];
+        } else if (IDXD) {
+          const uint32_t sG = g[c] != kNoState ? g[c] : toGlobal(s[c]);
+          const bool accepting = report && sG >= d.firstAccept && sG < d.nStates;
+          rr = d.result[accepting ? sG : 0u];
+          rr = accepting ? rr : 0;
+          en = len[c];
+        } else {
+          rr = ldsRes[s[c] & 0xffu];
+          rr = s[c] >= firstAccept ? rr : 0;
+          en = len[c];
+        }
+        const uint64_t at = ln[c];
+        uint8_t *dummy = const_cast<uint8_t *>(io.pad) + 192;
+        int32_t *rp = report ? io.result + at : reinterpret_cast<int32_t *>(dummy);
+        *rp = rr;
+        uint64_t *ep = report && io.end ? io.end + at : reinterpret_cast<uint64_t *>(dummy);
+        *ep = rr ? uint64_t(en) : 0;
         if (kStart) {
-          startv[c] = b[c].start ? off + b[c].start - 1 : startv[c];
-          const bool wasInit63 = (mA[c] >> (threadIdx.x & 63)) & 1;
-          if (full && wasInit63 && s[c] != init) startv[c] = off + 63;
+          uint64_t *sp = report && io.start ? io.start + at : reinterpret_cast<uint64_t *>(dummy);
+          *sp = rr ? uint64_t(st) : 0;
         }
       }
-    };
-
-    if (R) issue(A, 0);
-    for (uint32_t r = 0; r < R; r += 2) {
-      issue(B, r + 1);
-      walk(A, r);
-      issue(A, r + 2);
-      if (r + 1 < R) walk(B, r + 1);
-    }
-
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      if (!mine[c]) continue;
-      int32_t rr;
-      uint32_t en;
-      if (len[c] == 0) {
-        rr = initResult;  // no byte walked: the start state's own result, positions 0
-        en = 0;
-        startv[c] = 0;
-      } else if (kAcc) {
-        rr = endv[c] ? (IDXD ? d.result[accS[c]] : ldsRes[accS[c]]) : 0;
-        en = endv[c];
-      } else if (IDXD) {
-        const uint32_t sG = g[c] != kNoState ? g[c] : toGlobal(s[c]);
-        rr = sG >= d.firstAccept ? d.result[sG] : 0;
-        en = len[c];
+      if (ends[c]) {
+        have[c] = nHave[c]; ln[c] = nLn[c]; lineOff[c] = nOff[c]; len[c] = nLen[c];
+        done[c] = 0;
+        freshLine(c);
+        nHave[c] = tHave[c]; nLn[c] = tLn[c]; nOff[c] = pOff[c]; nLen[c] = pLen[c];
       } else {
-        rr = s[c] >= firstAccept ? ldsRes[s[c]] : 0;
-        en = len[c];
+        done[c] += 64u;
       }
-      io.result[ln[c]] = rr;
-      if (io.end) io.end[ln[c]] = rr ? uint64_t(en) : 0;
-      if (kStart && io.start) io.start[ln[c]] = rr ? uint64_t(startv[c]) : 0;
+      // a fresh line starts in the initial state, reached by a "valid" step
+      const uint64_t fresh = __builtin_amdgcn_ballot_w64(ends[c]);
+      mA[c] = uniform64(mA[c] | fresh);
+      vA[c] = uniform64(vA[c] | fresh);
     }
+  };
+
+  {
+    uint64_t first[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) first[c] = lineOff[c];
+    issueAt(A, first);
+  }
+  while (true) {
+    if (!__builtin_amdgcn_ballot_w64(have[0] || have[CH - 1])) break;
+    turn(A, B);
+    if (!__builtin_amdgcn_ballot_w64(have[0] || have[CH - 1])) break;
+    turn(B, A);
   }
 }
 
@@ -678,9 +806,11 @@ hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
   const uint64_t tiles = (b.n + linesPerTile - 1) / linesPerTile;
   const uint64_t blocks = tiles < uint64_t(cfg.numCUs) ? tiles : uint64_t(cfg.numCUs);
   Batch rb;
-  hipError_t e = prepareRagged(b, cfg, stream, true, rb);
+  LaunchCfg plain = cfg;
+  plain.noBucketing = 1;  // lines are handed out in input order: nothing to sort
+  hipError_t e = prepareRagged(b, plain, stream, true, rb);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_ragged<MODE, TABK>), dim3(uint32_t(blocks)), dim3(kStreamThreads), 0, stream,
-                     d, rb);
+  hipLaunchKernelGGL((k_ragged<MODE, TABK>), dim3(uint32_t(blocks)), dim3(kStreamThreads), 0,
+                     stream, d, rb);
   return hipGetLastError();
 }

@@ -1765,6 +1765,7 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
   // k_ragged walks every line; blocks that would reach past the end of the buffer come from a
   // padded copy of its last bytes.
   const bool raggedOk = !cfg.forceGeneric && !dying && fastPathEligible(d) && b.offsets &&
+                        b.n < (1ull << 32) &&
                         (verb == kCheck || verb == kMatch) &&
                         (style == kStyLast || style == kStyFull) && !lead &&
                         d.tableBytes <= kStreamTabBytes && d.nStates <= 256;
@@ -1789,6 +1790,7 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
   // redgpu_dfa_tune) - still ahead of k_generic on the same lines (98 GB/s: its one-line-per-
   // lane walk also pays the wave-max of the line lengths); without URLs 629 vs 107 GB/s.
   const bool hotRaggedOk = !cfg.forceGeneric && !dying && hotStreamEligible(d) && b.offsets &&
+                           b.n < (1ull << 32) &&
                            (verb == kCheck || verb == kMatch) &&
                            (style == kStyLast || style == kStyFull) && !lead;
   if (hotRaggedOk) {
@@ -1806,6 +1808,7 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
 
   // ... and for mid-size DFAs with a class table of at most 64 KB
   const bool clsRaggedOk = !cfg.forceGeneric && !dying && clsStreamEligible(d) && b.offsets &&
+                           b.n < (1ull << 32) &&
                            (verb == kCheck || verb == kMatch) &&
                            (style == kStyLast || style == kStyFull) && !lead;
   if (clsRaggedOk) {

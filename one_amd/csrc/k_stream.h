@@ -537,6 +537,38 @@ k_stream(DevDfa d, Batch io) {
         }
       }
     }
+    constexpr bool kPlainOut = !IDXD && MODE != kSmAdvance && MODE != kSmChunk;
+    if constexpr (kPlainOut) {
+      // Results are stored after EVERY block, without a branch: by lanes whose line ends here into
+      // the line's slots, by everyone else into the DFA's sink.  Stores under a branch are vm
+      // operations the compiler cannot count: the next walk's wait for its (older) input block
+      // then has to assume none was issued and ends up sitting out the stores' acknowledgements -
+      // once per tile, i.e. on every block of 64-byte lines.
+      const bool lineEnd = r + 1 == R;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const uint64_t ln = tile * linesPerTile + uint64_t(c) * THREADS + threadIdx.x;
+        const bool report = lineEnd && ln < io.n;
+        int32_t rr;
+        uint32_t en;
+        if (kAcc) {
+          rr = ldsRes[accS[c] & 0xffu];
+          rr = endv[c] ? rr : 0;
+          en = endv[c];
+        } else {
+          rr = ldsRes[s[c] & 0xffu];
+          rr = s[c] >= firstAccept ? rr : 0;
+          en = lineLen;
+        }
+        *(report ? io.result + ln : reinterpret_cast<int32_t *>(d.sink)) = rr;
+        *(report && io.end ? io.end + ln : reinterpret_cast<uint64_t *>(d.sink)) = rr ? uint64_t(en) : 0;
+        if (kStart)
+          *(report && io.start ? io.start + ln : reinterpret_cast<uint64_t *>(d.sink)) =
+              rr ? uint64_t(startv[c]) : 0;
+      }
+      if (++r == R) { r = 0; tile += G; }
+      return;
+    }
     if (++r == R) {
       r = 0;
 #pragma unroll
@@ -574,12 +606,20 @@ k_stream(DevDfa d, Batch io) {
   };
 
   if (!EARLY) issue(A);
-  for (uint64_t q = 0; q < Q; q += 2) {
-    if (q == 0 && (io.exp & 1u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // The loop is rotated by one block: both ways into its head (from here and around the back
+  // edge) then end in "block requested, a block's results stored, block requested", and the
+  // compiler's vmcnt for the head's walk - the minimum over the ways in - is exact.  Entered
+  // straight after the first request it would have to assume no store was pending and would
+  // sit out the previous block's result stores on every iteration.
+  issue(B);
+  walkBlock(A);
+  issue(A);
+  for (uint64_t q = 1; q < Q; q += 2) {
+    walkBlock(B);
+    if (q + 1 >= Q) break;
     issue(B);
     walkBlock(A);
     issue(A);
-    if (q + 1 < Q) walkBlock(B);
   }
 }
 
@@ -622,18 +662,12 @@ hipError_t launchStreamTT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
   const uint64_t tiles = (b.n + linesPerTile - 1) / linesPerTile;
   // one workgroup per CU: two (32 chains per CU) measured 26.0 us against 24.7 us on configs[1]
   const uint64_t blocks = tiles < uint64_t(cfg.numCUs) ? tiles : uint64_t(cfg.numCUs);
-  static const uint32_t exp = [] {
-    const char *e = getenv("REDGPU_EXP");
-    return e ? uint32_t(strtoul(e, nullptr, 0)) : 0u;
-  }();
-  Batch eb = b;
-  eb.exp = exp;
   if (b.stride % 128 == 0)
     hipLaunchKernelGGL((k_stream<MODE, 2, THREADS>), dim3(uint32_t(blocks)), dim3(THREADS), 0,
-                       stream, d, eb);
+                       stream, d, b);
   else
     hipLaunchKernelGGL((k_stream<MODE, 1, THREADS>), dim3(uint32_t(blocks)), dim3(THREADS), 0,
-                       stream, d, eb);
+                       stream, d, b);
   return hipGetLastError();
 }
 

@@ -14,6 +14,8 @@ struct DevDfa {
   const uint8_t *table;    // packed table, layout per tableKind (REDGPU_TAB_*)
   const int32_t *result;   // [nStates] result code per device state
   const uint8_t *equivLeader; // 256 bytes equivalence map, then 256 bytes class-space leader
+  uint8_t *sink;           // 64 writable bytes nobody reads: where lanes with nothing to report
+                           // store, so that result stores need no branch (k_stream.h)
   uint32_t tableKind;
   uint32_t tableBytes;
   uint32_t nStates;
@@ -50,7 +52,6 @@ struct Batch {
   uint32_t *state = nullptr; // advance only: per-line StatefulMatcher state, in/out
   const uint32_t *perm = nullptr; // k_ragged only: slot -> line (lines bucketed by length)
   const uint8_t *pad = nullptr;   // k_ragged only: copy of the buffer's last 128 bytes + zeros
-  uint32_t exp = 0;               // k_stream only: REDGPU_EXP experiment bits (tuning knob)
 };
 
 struct LaunchCfg {

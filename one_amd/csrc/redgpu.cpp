@@ -222,7 +222,7 @@ int uploadImage(SharedImage *im) {
   if ((e = hipMalloc(&im->dTable, tabBytes + 16)) != hipSuccess) return failHip(e, "hipMalloc table");
   if ((e = hipMalloc(&im->dResult, img.nStates * sizeof(int32_t) + 16)) != hipSuccess)
     return failHip(e, "hipMalloc result");
-  if ((e = hipMalloc(&im->dEquivLeader, 512)) != hipSuccess) return failHip(e, "hipMalloc equiv");
+  if ((e = hipMalloc(&im->dEquivLeader, 512 + 64)) != hipSuccess) return failHip(e, "hipMalloc equiv");
   if ((e = hipMemset(im->dTable, 0, tabBytes + 16)) != hipSuccess) return failHip(e, "hipMemset");
   if ((e = hipMemcpy(im->dTable, img.table.data(), img.table.size(), hipMemcpyHostToDevice)) !=
       hipSuccess)
@@ -237,6 +237,7 @@ int uploadImage(SharedImage *im) {
   d.table = static_cast<const uint8_t *>(im->dTable);
   d.result = static_cast<const int32_t *>(im->dResult);
   d.equivLeader = static_cast<const uint8_t *>(im->dEquivLeader);
+  d.sink = static_cast<uint8_t *>(im->dEquivLeader) + 512;
   d.tableKind = img.tableKind;
   d.tableBytes = (img.primaryBytes + 15u) & ~15u;  // the tableKind table only (LDS staging size)
   d.nStates = img.nStates;

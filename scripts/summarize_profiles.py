@@ -19,11 +19,12 @@ src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 for run in ("stats_default", "stats_1stream"):
-    for f in glob.glob(os.path.join(src, run, "*", "*_kernel_stats.csv")):
-        shutil.copy(f, os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, run[6:])))
+    found = sorted(glob.glob(os.path.join(src, run, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+    if found:  # the newest run only (gpurun merges into gpurun_out/, older runs' files stay)
+        shutil.copy(found[-1], os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, run[6:])))
 summary = {"kernel": None, "counters": {}, "launches": {}}
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
-    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+    for f in sorted(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1:]:
         agg = collections.defaultdict(list)
         for row in csv.DictReader(open(f)):
             if "k_stream" in row["Kernel_Name"]:

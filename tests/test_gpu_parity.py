@@ -983,7 +983,7 @@ def test_collect_on_gpu():
 
 @pytest.mark.parametrize("name", ["syn256", "uri", "dotstar_err", "newyork"])
 def test_ragged_stream_kernel_tail_and_shapes(name):
-    """k_ragged + its k_generic tail pass: lines ending inside the buffer's last 64 bytes, runs
+    """k_ragged: lines ending inside the buffer's last 64 bytes (read through the tail pad), runs
     of empty lines (also at the very end), buffers shorter than one block, block-multiple and
     block-multiple+-1 lengths, one very long line among short ones."""
     blob = load_dfa(name)
@@ -997,6 +997,9 @@ def test_ragged_stream_kernel_tail_and_shapes(name):
         list(rng.integers(0, 90, 3000)) + [0, 0, 1, 2, 0],
         [64] * 2050,                                 # whole blocks, > one tile
         [5000] + list(rng.integers(0, 40, 1500)),    # one line far longer than its wave-mates
+        # many workgroup ranges (69 of ~1014 lines), each drained through its LDS cursor
+        list(rng.integers(0, 200, 70000)),
+        [0] * 5000 + [70] + [0] * 5000,              # ranges made of empty lines only
     ]
     for lens in shapes:
         offsets = np.zeros(len(lens) + 1, dtype=np.uint64)

@@ -421,20 +421,24 @@ k_ragged(DevDfa d, Batch io) {
   // one block of every lane's current line: X holds it, Y receives the block after it
   auto turn = [&](const BlockRegs<1> (&X)[CH], BlockRegs<1> (&Y)[CH]) {
     bool ends[CH];
-    {
-      uint64_t follow[CH];
-#pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        ends[c] = !have[c] || done[c] + 64u >= len[c];
-        follow[c] = ends[c] ? (nHave[c] ? nOff[c] : 0) : lineOff[c] + done[c] + 64u;
-      }
-      issueAt(Y, follow);
-    }
+    // claim first, then request the block: the compiler moves the claimed offsets out of their
+    // load registers somewhere in the middle of the walk, and the wait it puts there must not
+    // cover the block requests (requested after the offsets they are not waited for: vmcnt(8))
     {
       bool want[CH];
 #pragma unroll
-      for (int c = 0; c < CH; ++c) want[c] = ends[c] && !dry[c];
+      for (int c = 0; c < CH; ++c) {
+        ends[c] = !have[c] || done[c] + 64u >= len[c];
+        want[c] = ends[c] && !dry[c];
+      }
       claim(want);
+    }
+    {
+      uint64_t follow[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+        follow[c] = ends[c] ? (nHave[c] ? nOff[c] : 0) : lineOff[c] + done[c] + 64u;
+      issueAt(Y, follow);
     }
     // loop-carried lane masks: pinned to SGPRs where the asm steps take them
 #pragma unroll

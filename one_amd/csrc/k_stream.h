@@ -6,8 +6,10 @@
 //
 // Shape, and why (every number below was measured on MI355X, tools/tune.hip):
 //  * One workgroup of 512 threads per CU shares one table copy (8 waves x 2 lines = 16 dependent
-//    chains per CU; 1024 threads saturate the LDS better in steady state but need twice the
-//    data before their first step - on 64 MiB batches 512 wins); staging it costs ~1.6 us and is
+//    chains per CU; 768 and 1024 threads - 3 and 4 waves per SIMD to hide the LDS latency a step
+//    waits for - win only on huge batches of 64-byte lines (2^24 x 64 B: 3.84 against 3.69 TB/s)
+//    and lose everywhere else (2^21 x 4 KiB: 3.92 / 3.45 against 4.25 TB/s; 2^20 x 64 B: 26.8
+//    against 24.7 us)); staging it costs ~1.6 us and is
 //    done BEFORE any input is requested - input requests issued earlier sit in front of the
 //    table's in the CU's memory queues and delay the table barrier to ~6 us.
 //  * Each lane walks 2 lines at once (two dependent chains per lane).  Input blocks are
@@ -409,7 +411,9 @@ k_stream(DevDfa d, Batch io) {
       reinterpret_cast<const uint4 *>(d.table + (HOT ? d.hot8Off : CLS ? d.clsOff : 0u));
   const uint32_t n16 = HOT ? kStreamTabBytes / 16 : CLS ? d.clsBytes / 16 : d.tableBytes / 16;
   // CLS: 256 bytes of eq2 in front of a table of up to 64 KB - one more 16-byte piece per thread
-  constexpr uint32_t kStagePieces = BIG ? 1 : kStreamTabBytes / 16 / THREADS + (CLS ? 1 : 0);
+  // 16-byte pieces per thread that cover the table (+ eq2's 256 B in the class-table form)
+  constexpr uint32_t kStagePieces =
+      BIG ? 1 : (kStreamTabBytes / 16 + (CLS ? 64 : 0) + THREADS - 1) / THREADS;
   uint4 tv[kStagePieces];
   if (BIG) {  // up to 155 KB: straight through, no register staging
     for (uint32_t i = threadIdx.x; i < n16; i += THREADS) reinterpret_cast<uint4 *>(tab)[i] = tsrc[i];
@@ -427,7 +431,8 @@ k_stream(DevDfa d, Batch io) {
 #pragma unroll
     for (uint32_t k = 0; k < kStagePieces; ++k) {
       const uint32_t i = k * THREADS + threadIdx.x;
-      if (!BIG && i < (kStreamTabBytes + 1024) / 16) dst[i] = tv[k];
+      // (the result words behind a fused / hot table are written below, by other threads)
+      if (!BIG && i < (kStreamTabBytes + (CLS ? 1024 : 0)) / 16) dst[i] = tv[k];
     }
     if (!CLS && threadIdx.x < 256) ldsRes[threadIdx.x] = myRes;
   }

@@ -81,6 +81,12 @@ typedef struct redgpu_opts {
                                        most-visited states (device states [hot_lo, hot_lo +
                                        n_hot)): entry = hot index of the target, 255 = the
                                        target is not hot (look it up in the class table) */
+#define REDGPU_TAB_LDS_SPARSE     7 /* class table too big for LDS but sparse (signature sets:
+                                       94 % of LOG-100's transitions lead to the dead state):
+                                       row-displacement ("comb") form in LDS - base[state] u16,
+                                       then u32 slots (owner state << 16 | target) at
+                                       base + class; a slot owned by another state means the
+                                       DFA's most common target */
 
 typedef struct redgpu_info {
   uint32_t format;        /* 1, 2, 4: FileHeader.format_ (include/Serializer.h:34-40,47) */

@@ -328,6 +328,83 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
     }  // wantHot
   }
 
+  // Sparse form (REDGPU_TAB_LDS_SPARSE).  A signature set - anchored patterns that share little -
+  // has a class table far too big for LDS of which almost every entry is the dead state
+  // (LOG-100: 3150 states x 40 classes = 252 KB, 5.9 % of the entries are anything else).  Its
+  // walks die within a few bytes on ordinary lines and run through one signature's private
+  // states on matching ones: no set of 254 hot rows covers those, every step of a match is an
+  // L2 round trip.  Row displacement (Tarjan & Yao's comb) packs the exceptions into one slot
+  // array - each row shifted until its exceptions fall on free slots, a slot remembering its
+  // owner - and the whole DFA sits in LDS: base[state], then slot[base + class].
+  // Taken only for early-death DFAs (they run on k_generic whatever the table) whose class
+  // table does not fit; a loose-start DFA keeps the hot-row streaming kernels.
+  std::vector<uint32_t> sparseBase;   // per device state (plain order)
+  std::vector<uint32_t> sparseSlot;   // (owner << 16) | target, 0xffff0000 = free
+  if (!forceGlobal && !forceHot && img.earlyDeath && reach.size() < 65535 &&
+      (fitKind == REDGPU_TAB_HOT_ROWS || fitKind == REDGPU_TAB_GLOBAL_U16)) {
+    std::vector<uint32_t> plain;
+    plain.reserve(reach.size());
+    for (int k = 0; k < 3; ++k)
+      for (uint32_t s : reach)
+        if (klass(s) == k) plain.push_back(s);
+    std::vector<uint32_t> idOf(stateCnt, 0xffffffffu);
+    for (uint32_t i = 0; i < plain.size(); ++i) idOf[plain[i]] = i;
+    const uint32_t nS = uint32_t(plain.size());
+    std::vector<uint32_t> tgt(size_t(nS) * nCls);
+    std::vector<uint32_t> freq(nS, 0);
+    for (uint32_t i = 0; i < nS; ++i)
+      for (uint32_t c = 0; c < nCls; ++c) {
+        uint32_t t = 0;
+        targetOf(plain[i], c, t);
+        tgt[size_t(i) * nCls + c] = idOf[t];
+        ++freq[idOf[t]];
+      }
+    const uint32_t dflt = uint32_t(std::max_element(freq.begin(), freq.end()) - freq.begin());
+    std::vector<uint32_t> rows(nS), cnt(nS, 0);
+    for (uint32_t i = 0; i < nS; ++i) {
+      rows[i] = i;
+      for (uint32_t c = 0; c < nCls; ++c) cnt[i] += tgt[size_t(i) * nCls + c] != dflt;
+    }
+    std::stable_sort(rows.begin(), rows.end(), [&](uint32_t a, uint32_t b) { return cnt[a] > cnt[b]; });
+    const uint64_t budgetSlots = ldsTableMax / 4u;
+    std::vector<uint8_t> used;
+    std::vector<uint32_t> base(nS, 0);
+    uint32_t firstFree = 0, top = 0;
+    bool ok = true;
+    for (uint32_t i : rows) {
+      if (cnt[i] == 0) continue;  // base 0: every lookup finds somebody else's slot or a free one
+      uint32_t b = firstFree;
+      for (;; ++b) {
+        if (uint64_t(b) + nCls > budgetSlots || b > 0xffffu - nCls) { ok = false; break; }
+        if (used.size() < size_t(b) + nCls) used.resize(size_t(b) + nCls, 0);
+        bool fits = true;
+        for (uint32_t c = 0; c < nCls && fits; ++c)
+          fits = tgt[size_t(i) * nCls + c] == dflt || !used[b + c];
+        if (fits) break;
+      }
+      if (!ok) break;
+      base[i] = b;
+      for (uint32_t c = 0; c < nCls; ++c)
+        if (tgt[size_t(i) * nCls + c] != dflt) { used[b + c] = 1; top = std::max(top, b + c + 1); }
+      while (firstFree < used.size() && used[firstFree]) ++firstFree;
+    }
+    const uint64_t baseBytes = (uint64_t(nS) * 2u + 15u) & ~uint64_t(15);
+    const uint64_t slots = uint64_t(top) + nCls;  // lookups of rows that own nothing up there stay inside
+    if (ok && baseBytes + slots * 4u <= ldsTableMax) {
+      img.tableKind = REDGPU_TAB_LDS_SPARSE;
+      img.nHot = 0;
+      img.hotCoveragePpm = 0;
+      std::fill(isHot.begin(), isHot.end(), 0);
+      img.sparseDefault = dflt;
+      sparseBase = base;
+      sparseSlot.assign(size_t(slots), 0xffff0000u);
+      for (uint32_t i = 0; i < nS; ++i)
+        for (uint32_t c = 0; c < nCls; ++c)
+          if (tgt[size_t(i) * nCls + c] != dflt)
+            sparseSlot[base[i] + c] = (i << 16) | tgt[size_t(i) * nCls + c];
+    }
+  }
+
   // order: pure dead ends | non-accepting | accepting (stable in blob order); with hot rows
   // the two middle groups are split cold | hot and hot | cold so the hot set is contiguous
   std::vector<uint32_t> order;
@@ -389,6 +466,17 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
     for (uint32_t i = 0; i < img.nStates; ++i)
       for (uint32_t b = 0; b < 256; ++b)
         put(size_t(i) * 256 + b, img.next[size_t(i) * nCls + img.equiv[b]], w);
+    break;
+  }
+  case REDGPU_TAB_LDS_SPARSE: {
+    // (device ids are the plain order the slots were packed in)
+    img.sparseCombOff = uint32_t((size_t(img.nStates) * 2u + 15u) & ~size_t(15));
+    img.table.assign(size_t(img.sparseCombOff) + sparseSlot.size() * 4u, 0);
+    for (uint32_t i = 0; i < img.nStates; ++i) {
+      const uint16_t b = uint16_t(sparseBase[i]);
+      std::memcpy(&img.table[size_t(i) * 2u], &b, 2);
+    }
+    std::memcpy(&img.table[img.sparseCombOff], sparseSlot.data(), sparseSlot.size() * 4u);
     break;
   }
   default: {

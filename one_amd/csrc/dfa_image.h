@@ -74,6 +74,10 @@ struct DfaImage {
   // ... and above 64 KB (up to what LDS holds) the same blob in INDEX form: entries are plain
   // state indices and the kernel multiplies (v_mad_u32_u24) instead of adding
   bool clsIndexForm = false;
+  // REDGPU_TAB_LDS_SPARSE: table = [base u16[nStates], padded to 16][slot u32[...]]; a slot is
+  // (owner state << 16) | target, 0xffff0000 when free; lookups of (state, class) read slot
+  // base[state] + class and fall back to sparseDefault when the owner is somebody else
+  uint32_t sparseCombOff = 0, sparseDefault = 0;
   uint32_t hotCoveragePpm = 0;    // modelled share of visits landing on hot rows
   bool     forgetful = false;     // the model's walk is back in the initial state most of the
                                   // time (>= 70 % of its mass after 64 bytes): chunks of a line

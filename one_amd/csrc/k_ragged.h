@@ -322,7 +322,9 @@ k_ragged(DevDfa d, Batch io) {
                                  : (init >= firstAccept ? ldsRes[init] : 0);
   // this workgroup's lines: the contiguous range [lo, lo + range).  (Handing them out longest
   // first through the bucketing pass's permutation - so that a long line cannot start last -
-  // measured slower at every shape: 591 against 706 GB/s on geometric lengths.)
+  // measured slower at every shape, 591 against 706 GB/s on geometric lengths: the sort costs
+  // 13 us, the lanes of a wave then read all over the buffer, and the permutation entry is a
+  // dependent load in front of the offsets.  DESIGN.md section 7 has what to try instead.)
   const uint64_t lo = io.n * blockIdx.x / gridDim.x;
   const uint32_t range = uint32_t(io.n * (blockIdx.x + 1) / gridDim.x - lo);
   const uint32_t lane = threadIdx.x & 63u;

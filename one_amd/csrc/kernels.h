@@ -31,6 +31,7 @@ struct DevDfa {
   uint32_t hotLo, nHot, hot8Off, hotShift;
   uint32_t clsOff, clsRowBytes, clsBytes;  // streaming form of the class table, or 0
   uint32_t clsIndexForm;         // its entries are state indices (tables above 64 KB), not row offsets
+  uint32_t sparseCombOff, sparseDefault;  // REDGPU_TAB_LDS_SPARSE: byte offset of the slots, default target
   uint32_t earlyDeath;           // the visit model sees walks die within 16 bytes
   uint32_t tuned;                // hot rows ranked by observed visits
   uint32_t forgetful;            // the walk is mostly in the initial state (k_chunk.h)

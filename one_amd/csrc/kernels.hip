@@ -120,6 +120,22 @@ template <> struct Tab<REDGPU_TAB_HOT_ROWS> {
   }
 };
 
+// Sparse rows (dfa_image.cpp): the whole DFA in LDS in row-displacement form.  Two dependent
+// LDS reads per byte (base[state], then the slot) instead of an L2 round trip.
+template <> struct Tab<REDGPU_TAB_LDS_SPARSE> {
+  static constexpr bool kInLds = true;
+  const uint16_t *base;
+  const uint32_t *slot;
+  const uint8_t *eq;
+  uint32_t dflt;
+  __device__ Tab(const uint8_t *tab, const uint8_t *equiv, uint32_t)
+      : base(reinterpret_cast<const uint16_t *>(tab)), slot(nullptr), eq(equiv), dflt(0) {}
+  __device__ __forceinline__ uint32_t next(uint32_t s, uint32_t byte) const {
+    const uint32_t e = slot[uint32_t(base[s]) + eq[byte]];
+    return (e >> 16) == s ? (e & 0xffffu) : dflt;
+  }
+};
+
 // What a workgroup stages behind its 512 bytes of equivalence map + leader, and the accessor
 // over it.  Whole table for the LDS kinds, the hot rows for REDGPU_TAB_HOT_ROWS, nothing else.
 template <int KIND>
@@ -149,6 +165,10 @@ __device__ __forceinline__ Tab<KIND> stageTab(const DevDfa &d, uint8_t *lds) {
     tab.hotLo = d.hotLo;
     tab.nHot = d.nHot;
     tab.shift = d.hotShift;
+  }
+  if constexpr (KIND == REDGPU_TAB_LDS_SPARSE) {
+    tab.slot = reinterpret_cast<const uint32_t *>(ldsTab + d.sparseCombOff);
+    tab.dflt = d.sparseDefault;
   }
   return tab;
 }
@@ -1465,6 +1485,8 @@ hipError_t launchCollect(const DevDfa &d, const Batch &b, uint64_t cap, uint64_t
     return launchCollectK<REDGPU_TAB_GLOBAL_U16>(d, b, cap, counts, cfg, stream);
   case REDGPU_TAB_HOT_ROWS:
     return launchCollectK<REDGPU_TAB_HOT_ROWS>(d, b, cap, counts, cfg, stream);
+  case REDGPU_TAB_LDS_SPARSE:
+    return launchCollectK<REDGPU_TAB_LDS_SPARSE>(d, b, cap, counts, cfg, stream);
   default:
     return launchCollectK<REDGPU_TAB_GLOBAL_U32>(d, b, cap, counts, cfg, stream);
   }
@@ -1477,6 +1499,7 @@ hipError_t launchCollect(const DevDfa &d, const Batch &b, uint64_t cap, uint64_t
   case REDGPU_TAB_LDS_CLASS_U16: return CALL(REDGPU_TAB_LDS_CLASS_U16);                   \
   case REDGPU_TAB_GLOBAL_U16: return CALL(REDGPU_TAB_GLOBAL_U16);                         \
   case REDGPU_TAB_HOT_ROWS: return CALL(REDGPU_TAB_HOT_ROWS);                               \
+  case REDGPU_TAB_LDS_SPARSE: return CALL(REDGPU_TAB_LDS_SPARSE);                         \
   default: return CALL(REDGPU_TAB_GLOBAL_U32);                                            \
   }
 
@@ -1836,6 +1859,8 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
     return launchGeneric<REDGPU_TAB_GLOBAL_U16>(d, b, verb, style, lead, cfg, stream);
   case REDGPU_TAB_HOT_ROWS:
     return launchGeneric<REDGPU_TAB_HOT_ROWS>(d, b, verb, style, lead, cfg, stream);
+  case REDGPU_TAB_LDS_SPARSE:
+    return launchGeneric<REDGPU_TAB_LDS_SPARSE>(d, b, verb, style, lead, cfg, stream);
   default:
     return launchGeneric<REDGPU_TAB_GLOBAL_U32>(d, b, verb, style, lead, cfg, stream);
   }

@@ -257,6 +257,8 @@ int uploadImage(SharedImage *im) {
   d.clsRowBytes = img.clsRowBytes;
   d.clsBytes = img.clsBytes;
   d.clsIndexForm = img.clsIndexForm ? 1 : 0;
+  d.sparseCombOff = img.sparseCombOff;
+  d.sparseDefault = img.sparseDefault;
   d.tuned = img.tuned ? 1 : 0;
   d.forgetful = img.forgetful ? 1 : 0;
   d.startLeadWord = img.startLeadWord;

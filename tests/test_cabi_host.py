@@ -90,7 +90,8 @@ def test_table_placement():
     # too big for LDS whole, but a real regex set with locality: hot rows in LDS (kind 6), one
     # contiguous range of device states that straddles first_accept
     for name in ("log100", "uri_v6"):
-        i = one_amd.Executable(load_dfa(name), device="none").info
+        # (left to itself the anchored signature set takes the sparse LDS form, below)
+        i = one_amd.Executable(load_dfa(name), device="none", force_hot=(name == "log100")).info
         assert i["table_kind"] == 6 and 8 <= i["n_hot"] <= 254 and i["hot_coverage_ppm"] > 990000
         assert i["n_pure_dead"] <= i["hot_lo"] <= i["first_accept"] <= i["hot_lo"] + i["n_hot"]
         assert i["hot_lo"] + i["n_hot"] <= i["states_used"]
@@ -98,6 +99,10 @@ def test_table_placement():
         assert small["table_kind"] == 6 and small["n_hot"] == 16
     assert one_amd.Executable(load_dfa("log100"), device="none",
                               force_global=True).info["table_kind"] == 4
+    # 94 % of LOG-100's transitions lead to the dead state and its walks die early: the whole
+    # DFA goes to LDS in row-displacement form (252 KB class table -> 36 KB)
+    i = one_amd.Executable(load_dfa("log100"), device="none").info
+    assert i["table_kind"] == 7 and i["n_hot"] == 0 and i["table_bytes"] < 48 * 1024
     # the anchored signature set dies within a few bytes of arbitrary text; the loose-start
     # URI regex never does
     assert one_amd.Executable(load_dfa("log100"), device="none").info["early_death"] == 1

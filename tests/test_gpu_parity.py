@@ -202,12 +202,76 @@ def test_hot_row_tables_vs_oracle(rows):
     for name in ("log100", "uri_v6"):
         vec = load_vectors(name)
         exe = one_amd.Executable(load_dfa(name), **({"lds_table_max": rows * 256} if rows else {}))
-        assert exe.info["table_kind"] == 6
+        # with >= 36 KB of budget the signature set fits LDS in its sparse form (kind 7)
+        assert exe.info["table_kind"] == (7 if name == "log100" and rows in (0, 200) else 6)
         for lead in (0, 1):
             r, s, e = one_amd.match_batch(exe, vec["data"], 4, lead, offsets=vec["offsets"])
             key = "match_4_%d_" % lead
             assert np.array_equal(r, vec[key + "res"]) and np.array_equal(s, vec[key + "start"])
             assert np.array_equal(e, vec[key + "end"])
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_sparse_lds_tables_vs_oracle(seed):
+    """REDGPU_TAB_LDS_SPARSE: a class table too big for LDS, mostly dead-state entries, packed in
+    row-displacement form.  Random sparse DFAs (88 % of the transitions lead to the error state,
+    so walks die early), every verb and style, with and without the leader flag, against the
+    oracle; half of the lines follow live transitions, so slots of many rows are read."""
+    from oracle.reda_writer import write_reda
+    n_st, n_cls = 2600, 56                                   # 291 KB class table
+    rng = np.random.default_rng(seed)
+    trans = rng.integers(1, n_st, size=(n_st, n_cls), dtype=np.int64)
+    trans[rng.random((n_st, n_cls)) < 0.88] = 0              # state 0 = the error state
+    trans[0, :] = 0
+    results = np.where(rng.random(n_st) < 0.2, rng.integers(1, 6, size=n_st), 0)
+    results[0] = results[1] = 0
+    equiv = rng.integers(0, n_cls, size=256, dtype=np.int64).astype(np.uint8)
+    equiv[:n_cls] = np.arange(n_cls, dtype=np.uint8)
+    blob = write_reda(trans, results, equiv=equiv, initial=1)
+    exe = one_amd.Executable(blob)
+    cpu = O.CpuOracle(blob)
+    assert exe.info["table_kind"] == 7 and exe.info["early_death"] == 1, exe.info
+    assert one_amd.Executable(blob, force_hot=True).info["table_kind"] == 6
+    lens = rng.integers(0, 120, 6000)
+    offsets = np.zeros(len(lens) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    data = rng.integers(0, 256, int(offsets[-1]), dtype=np.uint8)
+    # every other line starts with bytes that follow live transitions for as long as there are
+    # any (random bytes die after 1.1 steps on average: only the first rows would be read)
+    byte_of = [np.flatnonzero(equiv == c) for c in range(n_cls)]
+    for i in range(0, len(lens), 2):
+        st, o = 1, int(offsets[i])
+        for k in range(int(lens[i])):
+            live = np.flatnonzero(trans[st])
+            if live.size == 0:
+                break
+            c = int(live[rng.integers(0, live.size)])
+            data[o + k] = byte_of[c][rng.integers(0, byte_of[c].size)]
+            st = int(trans[st, c])
+    for si in range(1, 6):
+        for lead in (0, 1):
+            for verb, fn in (("match", one_amd.match_batch), ("search", one_amd.search_batch)):
+                er, es, ee = cpu.batch(verb, si, lead, data, offsets=offsets, threads=4)
+                r, s, e = fn(exe, data, si, lead, offsets=offsets)
+                assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee)
+            assert np.array_equal(one_amd.check_batch(exe, data, si, lead, offsets=offsets),
+                                  cpu.batch("check", si, lead, data, offsets=offsets)[0])
+            assert np.array_equal(one_amd.scan_batch(exe, data, si, lead, offsets=offsets),
+                                  cpu.batch("scan", si, lead, data, offsets=offsets, threads=4)[0])
+    state = np.full(len(lens), one_amd.STATE_INITIAL, dtype=np.uint32)
+    ostate = np.full(len(lens), O.STATE_INITIAL, dtype=np.uint32)
+    assert np.array_equal(one_amd.advance_batch(exe, data, state, offsets=offsets),
+                          cpu.advance_batch(data, ostate, offsets=offsets))
+    got = one_amd.match_all_batch(exe, data, 4, True, offsets=offsets)
+    exp = cpu.match_all_batch(data, 4, do_leader=True, offsets=offsets)
+    assert np.array_equal(got[0], exp[0])
+    # fixed-stride lines too (the early-exit generic kernel on every placement)
+    n, L = 3000, 64
+    d2 = rng.integers(0, 256, n * L, dtype=np.uint8)
+    for sty in (4, 5):
+        er, es, ee = cpu.batch("match", sty, 0, d2, stride=L, n=n, threads=4)
+        r, s, e = one_amd.match_batch(exe, d2, sty, 0, stride=L, n=n)
+        assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee)
 
 
 @pytest.mark.parametrize("case", ["uri_v6_random", "uri_v6_text", "log100_text", "random_cold",
@@ -227,7 +291,8 @@ def test_hot_row_streaming_kernel_vs_oracle(case):
         name = ("log100" if case.startswith("log100") else
                 "uri_user" if case.startswith("uri_user") else "uri_v6")
         blob = load_dfa(name)
-        exe = one_amd.Executable(blob, force_hot=(name == "uri_user"))
+        # (LOG-100 by itself takes the sparse LDS form, kind 7: hot rows only when forced)
+        exe = one_amd.Executable(blob, force_hot=(name in ("uri_user", "log100")))
         if case == "uri_user_text":
             # 343 states: the class table fits LDS; hot rows only when forced or after tuning
             mk = lambda n, L, seed: W.fixed_lines(n, L, seed, alphabet=True,

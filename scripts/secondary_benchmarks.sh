@@ -19,4 +19,5 @@ run prof_ragged.py uri_user
 run prof_ragged.py uri_user generic
 run prof_ragged.py uri_v6
 run prof_ragged.py uri_v6 generic
+run bench_log100.py
 echo secondary_done

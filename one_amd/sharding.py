@@ -128,10 +128,13 @@ def gather_outcomes(result, start, end, *, max_result: int, max_line_len: int, d
     if rec.shape[0] < n_max:
         padded = torch.zeros((n_max, fmt.bytes), dtype=torch.uint8, device=rec.device)
         padded[: rec.shape[0]] = rec
-    bufs = None
+    bufs = whole = None
     if rank == dst:
-        bufs = [torch.empty((n_max, fmt.bytes), dtype=torch.uint8, device=rec.device)
-                for _ in range(world)]
+        # one allocation, one view per rank: equal shards are then widened in ONE pass over the
+        # whole buffer (a dozen kernel launches on the root instead of a dozen per rank - the
+        # launches, not the bytes, are what a short timed region sees of the gather)
+        whole = torch.empty((world, n_max, fmt.bytes), dtype=torch.uint8, device=rec.device)
+        bufs = list(whole.unbind(0))
     work = dist.gather(padded, gather_list=bufs, dst=dst, group=group, async_op=async_op)
 
     def finish():
@@ -139,6 +142,8 @@ def gather_outcomes(result, start, end, *, max_result: int, max_line_len: int, d
             work.wait()
         if rank != dst:
             return None
+        if all(c == n_max for c in counts):
+            return fmt.unpack(whole.view(-1, fmt.bytes))
         parts = [fmt.unpack(bufs[r][: counts[r]]) for r in range(world)]
         res = torch.cat([p[0] for p in parts])
         st = torch.cat([p[1] for p in parts]) if fmt.with_start else None

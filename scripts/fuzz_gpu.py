@@ -42,7 +42,7 @@ def make_dfa():
         return name, load_dfa(name)
     n = int(rng.choice([2, 5, 17, 100, 255, 256, 257, 300, 800, 2500]))
     c = int(rng.choice([1, 2, 7, 30, 64, 128, 256]))
-    dead = float(rng.choice([0.0, 0.0, 0.01, 0.05, 0.3]))
+    dead = float(rng.choice([0.0, 0.0, 0.01, 0.05, 0.3, 0.9]))  # 0.9: sparse rows (kind 7) when big
     acc = float(rng.choice([0.0, 0.05, 0.2, 0.9]))
     s = int(rng.integers(0, 1 << 30))
     return "rnd(%d,%d,%d,dead=%.2f,acc=%.2f)" % (n, c, s, dead, acc), \

@@ -421,22 +421,32 @@ __device__ int32_t matchLane(const T &tab, const LaneCtx &c, const uint8_t *p, u
 // hand: with a leader, when its class is not the leader's first (compareThrough fails at k = 0:
 // the cursor stays put and the loop's ++in moves on - nothing else changes); without one, when
 // the first transition lands on a pure dead end.  Only the survivors touch memory again.
+// One scan in progress: the state scanCore's outer loop carries from start position to start
+// position, and visit() = one iteration of that loop for the position in hand.  Shared by the
+// per-lane walk (scanLane) and the candidate-list walk of k_scan_marked.
 template <class T>
-__device__ int32_t scanLane(const T &tab, const LaneCtx &c, const uint8_t *p, uint64_t n,
-                            int style, bool lead) {
-  int32_t result = c.resultOf(c.init);
-  int32_t ret = 0;
-  bool returned = false;
-  uint64_t resume = 0;  // the next start position the reference's outer loop would visit
-  const uint32_t lead0 = lead ? c.leader[0] : 0u;
-  const uint32_t lead1 = lead && c.leaderLen > 1 ? uint32_t(c.leader[1]) : kNoPeek;
-  // no start byte in a word: with the leader nothing changes (compareThrough fails at k = 0),
-  // without it each of the four attempts ends on a dead first step with result = 0
-  const int li = lead ? 1 : 0;
-  const StartFilter flt{c.startWord[li], c.startCount[li] <= 4 ? c.startCount[li] : 0u,
-                        c.start2Word[li], c.start2Count[li] <= 4 ? c.start2Count[li] : 0u, lead};
-  walkBytesPeek(p, 0, n, flt, [&]() { if (!lead) result = 0; },
-                [&](uint32_t byte, uint64_t i, uint32_t nextByte) {
+struct ScanWalk {
+  const T &tab;
+  const LaneCtx &c;
+  const uint8_t *p;
+  uint64_t n;
+  int style;
+  bool lead;
+  int32_t result, ret;
+  bool returned;
+  uint64_t resume;  // the next start position the reference's outer loop would visit
+  uint32_t lead0, lead1;
+  __device__ ScanWalk(const T &tab_, const LaneCtx &c_, const uint8_t *p_, uint64_t n_, int style_,
+                      bool lead_)
+      : tab(tab_), c(c_), p(p_), n(n_), style(style_), lead(lead_), result(c_.resultOf(c_.init)),
+        ret(0), returned(false), resume(0), lead0(lead_ ? c_.leader[0] : 0u),
+        lead1(lead_ && c_.leaderLen > 1 ? uint32_t(c_.leader[1]) : kNoPeek) {}
+  // positions stepped over because no attempt can survive there: with the leader nothing changes
+  // (compareThrough fails at k = 0), without it each attempt ends on a dead first step, result 0
+  __device__ __forceinline__ void skipped() { if (!lead) result = 0; }
+  __device__ __forceinline__ int32_t value() const { return returned ? ret : result; }
+  // false = the scan has returned
+  __device__ bool visit(uint32_t byte, uint64_t i, uint32_t nextByte) {
     if (i < resume) return true;
     uint32_t s;
     uint64_t q;  // the inner walk reads p[q..n)
@@ -497,8 +507,19 @@ __device__ int32_t scanLane(const T &tab, const LaneCtx &c, const uint8_t *p, ui
     if (style == kStyLast && result == 0 && prev > 0) { ret = prev; returned = true; return false; }
     if (result > 0) { ret = result; returned = true; return false; }
     return true;
-  });
-  return returned ? ret : result;
+  }
+};
+
+template <class T>
+__device__ int32_t scanLane(const T &tab, const LaneCtx &c, const uint8_t *p, uint64_t n,
+                            int style, bool lead) {
+  ScanWalk<T> w(tab, c, p, n, style, lead);
+  const int li = lead ? 1 : 0;
+  const StartFilter flt{c.startWord[li], c.startCount[li] <= 4 ? c.startCount[li] : 0u,
+                        c.start2Word[li], c.start2Count[li] <= 4 ? c.start2Count[li] : 0u, lead};
+  walkBytesPeek(p, 0, n, flt, [&]() { w.skipped(); },
+                [&](uint32_t byte, uint64_t i, uint32_t nextByte) { return w.visit(byte, i, nextByte); });
+  return w.value();
 }
 
 // include/Matcher.h:557-640 searchCore: sliding-window match; the leader is only PEEKED
@@ -621,6 +642,131 @@ k_generic(DevDfa d, Batch b, int style, int lead) {
       if (b.start) b.start[line] = st;
       if (b.end) b.end[line] = en;
     }
+  }
+}
+
+// =========================================================================================
+// k_scan_marked: scan (include/Matcher.h:498-554) in two passes per batch of lines.
+//
+// scanLane gives a lane a line and lets it step over the start positions; on text nearly all of
+// them are rejected from the byte in hand, but the rejecting is done 64 lines wide, a few
+// instructions per position, with every lane's candidate dragging the wave through the slow
+// path.  Here a workgroup takes up to kThreads consecutive lines at a time - a contiguous
+// piece of the input buffer - and
+//   1. MARKS: all threads sweep that piece 16 bytes per lane (coalesced, every byte read once),
+//      test each byte against the DFA's start bytes (the <= 4 bytes at which an attempt can
+//      survive its first step; with the leader: the bytes of the leader's first class) and
+//      leave one bit per position in LDS;
+//   2. VISITS: lane t takes line t and calls ScanWalk::visit() - the reference's loop body,
+//      the same code scanLane runs - for the marked positions of its line only, in order.
+// An unmarked position changes nothing but "result = 0" (without the leader) or nothing at all
+// (with it), which ScanWalk::skipped() stands for; a marked one that the partly matched
+// leader of an earlier attempt consumed is recognised by visit() itself (resume).
+// A line longer than the bitmap covers (256 KB) is scanned by one lane the old way.
+// =========================================================================================
+constexpr uint32_t kMarkBytes = 32768;  // bitmap bytes in LDS: one bit per input byte of a batch
+
+// one bit per byte of `word` that can start a surviving attempt: walkBytesPeek's test - a start
+// byte, followed (n2 != 0) by a byte that may follow one or, with the leader, by another start
+// byte (StartFilter::consumes)
+__device__ __forceinline__ uint32_t markNibble(uint32_t word, uint32_t nextWord, const StartFilter &f) {
+  uint32_t m = wordMatchMask(word, f.set1, f.n1);
+  if (m && f.n2) {
+    const uint32_t follow = (word >> 8) | (nextWord << 24);
+    uint32_t ok = wordMatchMask(follow, f.set2, f.n2);
+    if (f.consumes) ok |= wordMatchMask(follow, f.set1, f.n1);
+    m &= ok;
+  }
+  return ((m >> 7) & 1u) | ((m >> 14) & 2u) | ((m >> 21) & 4u) | ((m >> 28) & 8u);
+}
+
+template <int KIND, int kThreads>
+__global__ void __launch_bounds__(kThreads)
+k_scan_marked(DevDfa d, Batch b, int style, int lead) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  uint8_t *eq = lds;
+  uint8_t *leader = lds + 256;
+  const Tab<KIND> tab = stageTab<KIND, kThreads>(d, lds);
+  uint16_t *marks16 = reinterpret_cast<uint16_t *>(lds + 512 + ((ldsTableBytes<KIND>(d) + 15) & ~size_t(15)));
+  const uint32_t *marks32 = reinterpret_cast<const uint32_t *>(marks16);
+  LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
+            d.leaderLen};
+  const uint32_t n2 = lead ? d.start2LeadCount : d.start2FreeCount;
+  const StartFilter flt{lead ? d.startLeadWord : d.startFreeWord,
+                        lead ? d.startLeadCount : d.startFreeCount,  // 1..4 (launchGeneric)
+                        lead ? d.start2LeadWord : d.start2FreeWord, n2 <= 4 ? n2 : 0u, lead != 0};
+  const uint64_t dataAddr = reinterpret_cast<uint64_t>(b.data);
+  auto lineStart = [&](uint64_t line) -> uint64_t {
+    return b.offsets ? b.offsets[line] : line * b.stride;
+  };
+  const uint64_t lo = b.n * blockIdx.x / gridDim.x, hi = b.n * (blockIdx.x + 1) / gridDim.x;
+  for (uint64_t a = lo; a < hi;) {
+    // as many lines as the bitmap covers (workgroup-uniform)
+    uint64_t cnt = hi - a < uint64_t(kThreads) ? hi - a : uint64_t(kThreads);
+    const uint64_t first = lineStart(a);
+    const uint64_t baseAddr = (dataAddr + first) & ~15ull;
+    uint64_t last = lineStart(a + cnt);
+    while (cnt > 1 && dataAddr + last - baseAddr > uint64_t(kMarkBytes) * 8) {
+      cnt >>= 1;
+      last = lineStart(a + cnt);
+    }
+    const bool tooLong = dataAddr + last - baseAddr > uint64_t(kMarkBytes) * 8;  // cnt == 1
+    if (!tooLong) {
+      const uint64_t pieces = (dataAddr + last - baseAddr + 15) >> 4;
+      for (uint64_t k = threadIdx.x; k < pieces; k += kThreads) {
+        // (the first and the last piece may reach up to 15 bytes outside the buffer - inside a
+        // 16-byte granule that holds valid bytes; those bits are never looked at)
+        const uint4 v = *reinterpret_cast<const uint4 *>(baseAddr + 16 * k);
+        // the follower of the piece's last byte: the next piece's first (it exists - the walk of
+        // a line's LAST position is the same with or without a mark - except behind the last
+        // piece, where a byte nothing may follow keeps every start byte marked)
+        uint32_t after = 0;
+        if (k + 1 < pieces) after = *reinterpret_cast<const uint32_t *>(baseAddr + 16 * k + 16);
+        StartFilter f = flt;
+        if (k + 1 >= pieces) f.n2 = 0;
+        marks16[k] = uint16_t(markNibble(v.x, v.y, flt) | (markNibble(v.y, v.z, flt) << 4) |
+                              (markNibble(v.z, v.w, flt) << 8) | (markNibble(v.w, after, f) << 12));
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < cnt) {
+      const uint64_t line = a + threadIdx.x;
+      const uint64_t o = lineStart(line);
+      uint64_t n;
+      if (b.offsets) {
+        const uint64_t e = b.offsets[line + 1];
+        n = e - o >= b.stride ? e - o - b.stride : 0;  // stride = trailing bytes to drop (ragged)
+      } else {
+        n = b.stride;
+      }
+      const uint8_t *p = b.data + o;
+      int32_t r;
+      if (tooLong) {
+        r = scanLane(tab, c, p, n, style, lead != 0);
+      } else {
+        ScanWalk<Tab<KIND>> w(tab, c, p, n, style, lead != 0);
+        const uint64_t bit0 = dataAddr + o - baseAddr;  // this line's first bit
+        bool going = true;
+        for (uint64_t wd = bit0 >> 5; going && (wd << 5) < bit0 + n; ++wd) {
+          uint32_t m = marks32[wd];
+          const uint64_t wordBit = wd << 5;
+          if (wordBit < bit0) m &= ~0u << uint32_t(bit0 - wordBit);
+          if (wordBit + 32 > bit0 + n) m &= ~0u >> uint32_t(wordBit + 32 - (bit0 + n));
+          while (m) {
+            const uint32_t k = uint32_t(__builtin_ctz(m));
+            m &= m - 1;
+            const uint64_t i = wordBit + k - bit0;
+            w.skipped();  // harmless when nothing was: a visit that does not return leaves 0
+            if (!w.visit(p[i], i, i + 1 < n ? uint32_t(p[i + 1]) : kNoPeek)) { going = false; break; }
+          }
+        }
+        if (going && n) w.skipped();
+        r = w.value();
+      }
+      b.result[line] = r;
+    }
+    __syncthreads();
+    a += cnt;
   }
 }
 
@@ -1319,6 +1465,21 @@ hipError_t launchGeneric(const DevDfa &d, const Batch &b, int verb, int style, i
     hipLaunchKernelGGL((k_generic<KIND, kThreads, V>), dim3(uint32_t(blocks)), dim3(kThreads), \
                        ldsBytes, stream, d, pb, style, lead);                                \
   } while (0)
+  // scan over a DFA with at most 4 start bytes: mark the candidates, visit only those
+  const uint32_t scanStarts = lead ? d.startLeadCount : d.startFreeCount;
+  if (verb == kScan && scanStarts >= 1 && scanStarts <= 4 && !cfg.forceGeneric) {
+    const size_t markLds = 512 + ((ldsTableBytes<KIND>(d) + 15) & ~size_t(15)) + kMarkBytes;
+    if (markLds <= 160 * 1024 - 1024) {
+      hipError_t e_ = setLds(k_scan_marked<KIND, kThreads>, markLds);
+      if (e_ != hipSuccess) return e_;
+      uint64_t mb = (b.n + kThreads - 1) / kThreads;
+      const uint64_t mcap = uint64_t(cfg.numCUs) * (kLds ? (markLds <= 76 * 1024 ? 2 : 1) : 8);
+      if (mb > mcap) mb = mcap;
+      hipLaunchKernelGGL((k_scan_marked<KIND, kThreads>), dim3(uint32_t(mb)), dim3(kThreads), markLds,
+                         stream, d, b, style, lead);
+      return hipGetLastError();
+    }
+  }
   // whole-line walks over ragged lines profit from the length bucketing; walks that die in
   // their first bytes (early-death DFAs under check / match) do not care how long the line is
   Batch pb = b;
@@ -1847,7 +2008,11 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
     return d.clsIndexForm ? launchRaggedT<kSmFull, kTabClsBig>(d, sb, cfg, stream) : launchRaggedT<kSmFull, kTabCls>(d, sb, cfg, stream);
   }
 
-  *kernelName = "k_generic";
+  {
+    const uint32_t scanStarts = lead ? d.startLeadCount : d.startFreeCount;
+    *kernelName = verb == kScan && scanStarts >= 1 && scanStarts <= 4 && !cfg.forceGeneric
+                      ? "k_scan_marked" : "k_generic";
+  }
   switch (d.tableKind) {
   case REDGPU_TAB_LDS_FUSED_U8:
     return launchGeneric<REDGPU_TAB_LDS_FUSED_U8>(d, b, verb, style, lead, cfg, stream);

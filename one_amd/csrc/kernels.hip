@@ -662,9 +662,14 @@ k_generic(DevDfa d, Batch b, int style, int lead) {
 // An unmarked position changes nothing but "result = 0" (without the leader) or nothing at all
 // (with it), which ScanWalk::skipped() stands for; a marked one that the partly matched
 // leader of an earlier attempt consumed is recognised by visit() itself (resume).
-// A line longer than the bitmap covers (256 KB) is scanned by one lane the old way.
+// A line longer than the bitmap covers (64 KB) is scanned by one lane the old way.
 // =========================================================================================
-constexpr uint32_t kMarkBytes = 32768;  // bitmap bytes in LDS: one bit per input byte of a batch
+// 256 lines per batch, one bit per input byte in LDS (64 KB of input): small workgroups, several
+// per CU - a batch is a chain of dependent steps (offsets, marks, barrier, visits, barrier) and
+// only other workgroups can fill its gaps (1024-thread workgroups, one or two per CU: 116 us
+// for the batch that now takes ~half)
+constexpr uint32_t kMarkBytes = 8192;
+constexpr int kScanThreads = 256;
 
 // one bit per byte of `word` that can start a surviving attempt: walkBytesPeek's test - a start
 // byte, followed (n2 != 0) by a byte that may follow one or, with the leader, by another start
@@ -711,34 +716,44 @@ k_scan_marked(DevDfa d, Batch b, int style, int lead) {
       last = lineStart(a + cnt);
     }
     const bool tooLong = dataAddr + last - baseAddr > uint64_t(kMarkBytes) * 8;  // cnt == 1
+    // this lane's line (requested now, used after the marking)
+    const uint64_t line = a + (threadIdx.x < cnt ? threadIdx.x : 0);
+    const uint64_t o = lineStart(line);
+    const uint64_t oEnd = b.offsets ? b.offsets[line + 1] : o + b.stride;
     if (!tooLong) {
       const uint64_t pieces = (dataAddr + last - baseAddr + 15) >> 4;
-      for (uint64_t k = threadIdx.x; k < pieces; k += kThreads) {
-        // (the first and the last piece may reach up to 15 bytes outside the buffer - inside a
-        // 16-byte granule that holds valid bytes; those bits are never looked at)
-        const uint4 v = *reinterpret_cast<const uint4 *>(baseAddr + 16 * k);
-        // the follower of the piece's last byte: the next piece's first (it exists - the walk of
-        // a line's LAST position is the same with or without a mark - except behind the last
-        // piece, where a byte nothing may follow keeps every start byte marked)
-        uint32_t after = 0;
-        if (k + 1 < pieces) after = *reinterpret_cast<const uint32_t *>(baseAddr + 16 * k + 16);
-        StartFilter f = flt;
-        if (k + 1 >= pieces) f.n2 = 0;
-        marks16[k] = uint16_t(markNibble(v.x, v.y, flt) | (markNibble(v.y, v.z, flt) << 4) |
-                              (markNibble(v.z, v.w, flt) << 8) | (markNibble(v.w, after, f) << 12));
+      // four pieces per thread and trip, requested together
+      for (uint64_t k0 = threadIdx.x; k0 < pieces; k0 += 4ull * kThreads) {
+        uint4 v[4];
+        uint32_t after[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint64_t k = k0 + uint64_t(j) * kThreads;
+          // (the first and the last piece may reach up to 15 bytes outside the buffer - inside a
+          // 16-byte granule that holds valid bytes; those bits are never looked at)
+          const uint64_t kk = k < pieces ? k : pieces - 1;
+          v[j] = *reinterpret_cast<const uint4 *>(baseAddr + 16 * kk);
+          // the follower of the piece's last byte: the next piece's first (it exists - the walk
+          // of a line's LAST position is the same with or without a mark - except behind the
+          // last piece, where a byte nothing may follow keeps every start byte marked)
+          after[j] = *reinterpret_cast<const uint32_t *>(baseAddr + 16 * (kk + 1 < pieces ? kk + 1 : kk));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint64_t k = k0 + uint64_t(j) * kThreads;
+          if (k >= pieces) break;
+          StartFilter f = flt;
+          if (k + 1 >= pieces) f.n2 = 0;
+          marks16[k] = uint16_t(markNibble(v[j].x, v[j].y, flt) | (markNibble(v[j].y, v[j].z, flt) << 4) |
+                                (markNibble(v[j].z, v[j].w, flt) << 8) |
+                                (markNibble(v[j].w, after[j], f) << 12));
+        }
       }
     }
     __syncthreads();
     if (threadIdx.x < cnt) {
-      const uint64_t line = a + threadIdx.x;
-      const uint64_t o = lineStart(line);
-      uint64_t n;
-      if (b.offsets) {
-        const uint64_t e = b.offsets[line + 1];
-        n = e - o >= b.stride ? e - o - b.stride : 0;  // stride = trailing bytes to drop (ragged)
-      } else {
-        n = b.stride;
-      }
+      const uint64_t n = b.offsets ? (oEnd - o >= b.stride ? oEnd - o - b.stride : 0)  // stride =
+                                   : b.stride;                    // trailing bytes to drop (ragged)
       const uint8_t *p = b.data + o;
       int32_t r;
       if (tooLong) {
@@ -1470,13 +1485,14 @@ hipError_t launchGeneric(const DevDfa &d, const Batch &b, int verb, int style, i
   if (verb == kScan && scanStarts >= 1 && scanStarts <= 4 && !cfg.forceGeneric) {
     const size_t markLds = 512 + ((ldsTableBytes<KIND>(d) + 15) & ~size_t(15)) + kMarkBytes;
     if (markLds <= 160 * 1024 - 1024) {
-      hipError_t e_ = setLds(k_scan_marked<KIND, kThreads>, markLds);
+      hipError_t e_ = setLds(k_scan_marked<KIND, kScanThreads>, markLds);
       if (e_ != hipSuccess) return e_;
-      uint64_t mb = (b.n + kThreads - 1) / kThreads;
-      const uint64_t mcap = uint64_t(cfg.numCUs) * (kLds ? (markLds <= 76 * 1024 ? 2 : 1) : 8);
+      uint64_t mb = (b.n + kScanThreads - 1) / kScanThreads;
+      const uint64_t fit = (158 * 1024) / markLds;  // workgroups per CU by LDS
+      const uint64_t mcap = uint64_t(cfg.numCUs) * (fit < 8 ? fit : 8);
       if (mb > mcap) mb = mcap;
-      hipLaunchKernelGGL((k_scan_marked<KIND, kThreads>), dim3(uint32_t(mb)), dim3(kThreads), markLds,
-                         stream, d, b, style, lead);
+      hipLaunchKernelGGL((k_scan_marked<KIND, kScanThreads>), dim3(uint32_t(mb)), dim3(kScanThreads),
+                         markLds, stream, d, b, style, lead);
       return hipGetLastError();
     }
   }

@@ -26,6 +26,7 @@
 #include "kernels.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "../../include/redgpu.h"
 
@@ -525,20 +526,26 @@ __device__ int32_t scanLane(const T &tab, const LaneCtx &c, const uint8_t *p, ui
 // include/Matcher.h:557-640 searchCore: sliding-window match; the leader is only PEEKED
 // (lookingAt), so no start position is skipped - unlike scanCore.  Start positions come
 // through walkBytes and are rejected from the byte in hand like scanLane's.
+// searchLane's loop body as an object, like ScanWalk (shared with k_scan_marked)
 template <class T>
-__device__ int32_t searchLane(const T &tab, const LaneCtx &c, const uint8_t *p, uint64_t n,
-                              int style, bool lead, uint64_t &startOut, uint64_t &endOut) {
-  startOut = 0;
-  endOut = 0;
-  int32_t result = c.resultOf(c.init);
-  uint64_t matchStart = 0, matchEnd = 0;
-  const uint32_t lead0 = lead ? c.leader[0] : 0u;
-  const uint32_t lead1 = lead && c.leaderLen > 1 ? uint32_t(c.leader[1]) : kNoPeek;
-  const int li = lead ? 1 : 0;
-  const StartFilter flt{c.startWord[li], c.startCount[li] <= 4 ? c.startCount[li] : 0u,
-                        c.start2Word[li], c.start2Count[li] <= 4 ? c.start2Count[li] : 0u, false};
-  walkBytesPeek(p, 0, n, flt, [&]() { if (!lead) result = 0; },
-                [&](uint32_t byte, uint64_t idx, uint32_t nextByte) {
+struct SearchWalk {
+  const T &tab;
+  const LaneCtx &c;
+  const uint8_t *p;
+  uint64_t n;
+  int style;
+  bool lead;
+  int32_t result;
+  uint64_t matchStart, matchEnd;
+  uint32_t lead0, lead1;
+  __device__ SearchWalk(const T &tab_, const LaneCtx &c_, const uint8_t *p_, uint64_t n_, int style_,
+                        bool lead_)
+      : tab(tab_), c(c_), p(p_), n(n_), style(style_), lead(lead_), result(c_.resultOf(c_.init)),
+        matchStart(0), matchEnd(0), lead0(lead_ ? c_.leader[0] : 0u),
+        lead1(lead_ && c_.leaderLen > 1 ? uint32_t(c_.leader[1]) : kNoPeek) {}
+  __device__ __forceinline__ void skipped() { if (!lead) result = 0; }
+  // false = the search has found its match
+  __device__ bool visit(uint32_t byte, uint64_t idx, uint32_t nextByte) {
     if (lead) {
       if (c.eq[byte] != lead0) return true;
       if (lead1 != kNoPeek && nextByte != kNoPeek && c.eq[nextByte] != lead1) return true;
@@ -587,12 +594,25 @@ __device__ int32_t searchLane(const T &tab, const LaneCtx &c, const uint8_t *p, 
     }
     if ((style == kStyTangent || style == kStyLast) && result == 0 && prev > 0) result = prev;
     return !(result > 0);
-  });
-  if (result != 0) {
-    startOut = matchStart;
-    endOut = matchEnd;
   }
-  return result;
+};
+
+template <class T>
+__device__ int32_t searchLane(const T &tab, const LaneCtx &c, const uint8_t *p, uint64_t n,
+                              int style, bool lead, uint64_t &startOut, uint64_t &endOut) {
+  startOut = 0;
+  endOut = 0;
+  SearchWalk<T> w(tab, c, p, n, style, lead);
+  const int li = lead ? 1 : 0;
+  const StartFilter flt{c.startWord[li], c.startCount[li] <= 4 ? c.startCount[li] : 0u,
+                        c.start2Word[li], c.start2Count[li] <= 4 ? c.start2Count[li] : 0u, false};
+  walkBytesPeek(p, 0, n, flt, [&]() { w.skipped(); },
+                [&](uint32_t byte, uint64_t idx, uint32_t nextByte) { return w.visit(byte, idx, nextByte); });
+  if (w.result != 0) {
+    startOut = w.matchStart;
+    endOut = w.matchEnd;
+  }
+  return w.result;
 }
 
 // dynamic LDS: [equiv 256][leader 256][table (LDS kinds only)].  An LDS-resident table is
@@ -685,9 +705,10 @@ __device__ __forceinline__ uint32_t markNibble(uint32_t word, uint32_t nextWord,
   return ((m >> 7) & 1u) | ((m >> 14) & 2u) | ((m >> 21) & 4u) | ((m >> 28) & 8u);
 }
 
-template <int KIND, int kThreads>
+template <int KIND, int kThreads, int VERB>
 __global__ void __launch_bounds__(kThreads)
 k_scan_marked(DevDfa d, Batch b, int style, int lead) {
+  constexpr bool kSearchVerb = VERB == kSearch;
   extern __shared__ __align__(16) uint8_t lds[];
   uint8_t *eq = lds;
   uint8_t *leader = lds + 256;
@@ -699,7 +720,8 @@ k_scan_marked(DevDfa d, Batch b, int style, int lead) {
   const uint32_t n2 = lead ? d.start2LeadCount : d.start2FreeCount;
   const StartFilter flt{lead ? d.startLeadWord : d.startFreeWord,
                         lead ? d.startLeadCount : d.startFreeCount,  // 1..4 (launchGeneric)
-                        lead ? d.start2LeadWord : d.start2FreeWord, n2 <= 4 ? n2 : 0u, lead != 0};
+                        lead ? d.start2LeadWord : d.start2FreeWord, n2 <= 4 ? n2 : 0u,
+                        !kSearchVerb && lead != 0};  // search only peeks at the leader (lookingAt)
   const uint64_t dataAddr = reinterpret_cast<uint64_t>(b.data);
   auto lineStart = [&](uint64_t line) -> uint64_t {
     return b.offsets ? b.offsets[line] : line * b.stride;
@@ -756,10 +778,13 @@ k_scan_marked(DevDfa d, Batch b, int style, int lead) {
                                    : b.stride;                    // trailing bytes to drop (ragged)
       const uint8_t *p = b.data + o;
       int32_t r;
+      uint64_t st = 0, en = 0;
       if (tooLong) {
-        r = scanLane(tab, c, p, n, style, lead != 0);
+        if (kSearchVerb) r = searchLane(tab, c, p, n, style, lead != 0, st, en);
+        else r = scanLane(tab, c, p, n, style, lead != 0);
       } else {
-        ScanWalk<Tab<KIND>> w(tab, c, p, n, style, lead != 0);
+        typename std::conditional<kSearchVerb, SearchWalk<Tab<KIND>>, ScanWalk<Tab<KIND>>>::type
+            w(tab, c, p, n, style, lead != 0);
         const uint64_t bit0 = dataAddr + o - baseAddr;  // this line's first bit
         bool going = true;
         for (uint64_t wd = bit0 >> 5; going && (wd << 5) < bit0 + n; ++wd) {
@@ -776,9 +801,18 @@ k_scan_marked(DevDfa d, Batch b, int style, int lead) {
           }
         }
         if (going && n) w.skipped();
-        r = w.value();
+        if constexpr (kSearchVerb) {
+          r = w.result;
+          if (r != 0) { st = w.matchStart; en = w.matchEnd; }
+        } else {
+          r = w.value();
+        }
       }
       b.result[line] = r;
+      if (kSearchVerb) {
+        if (b.start) b.start[line] = st;
+        if (b.end) b.end[line] = en;
+      }
     }
     __syncthreads();
     a += cnt;
@@ -1480,19 +1514,24 @@ hipError_t launchGeneric(const DevDfa &d, const Batch &b, int verb, int style, i
     hipLaunchKernelGGL((k_generic<KIND, kThreads, V>), dim3(uint32_t(blocks)), dim3(kThreads), \
                        ldsBytes, stream, d, pb, style, lead);                                \
   } while (0)
-  // scan over a DFA with at most 4 start bytes: mark the candidates, visit only those
+  // scan / search over a DFA with at most 4 start bytes: mark the candidates, visit only those
   const uint32_t scanStarts = lead ? d.startLeadCount : d.startFreeCount;
-  if (verb == kScan && scanStarts >= 1 && scanStarts <= 4 && !cfg.forceGeneric) {
+  if ((verb == kScan || verb == kSearch) && scanStarts >= 1 && scanStarts <= 4 && !cfg.forceGeneric) {
     const size_t markLds = 512 + ((ldsTableBytes<KIND>(d) + 15) & ~size_t(15)) + kMarkBytes;
-    if (markLds <= 160 * 1024 - 1024) {
-      hipError_t e_ = setLds(k_scan_marked<KIND, kScanThreads>, markLds);
+    if (markLds <= 158 * 1024) {
+      hipError_t e_ = verb == kScan ? setLds(k_scan_marked<KIND, kScanThreads, kScan>, markLds)
+                                    : setLds(k_scan_marked<KIND, kScanThreads, kSearch>, markLds);
       if (e_ != hipSuccess) return e_;
       uint64_t mb = (b.n + kScanThreads - 1) / kScanThreads;
       const uint64_t fit = (158 * 1024) / markLds;  // workgroups per CU by LDS
       const uint64_t mcap = uint64_t(cfg.numCUs) * (fit < 8 ? fit : 8);
       if (mb > mcap) mb = mcap;
-      hipLaunchKernelGGL((k_scan_marked<KIND, kScanThreads>), dim3(uint32_t(mb)), dim3(kScanThreads),
-                         markLds, stream, d, b, style, lead);
+      if (verb == kScan)
+        hipLaunchKernelGGL((k_scan_marked<KIND, kScanThreads, kScan>), dim3(uint32_t(mb)),
+                           dim3(kScanThreads), markLds, stream, d, b, style, lead);
+      else
+        hipLaunchKernelGGL((k_scan_marked<KIND, kScanThreads, kSearch>), dim3(uint32_t(mb)),
+                           dim3(kScanThreads), markLds, stream, d, b, style, lead);
       return hipGetLastError();
     }
   }
@@ -2026,7 +2065,8 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
 
   {
     const uint32_t scanStarts = lead ? d.startLeadCount : d.startFreeCount;
-    *kernelName = verb == kScan && scanStarts >= 1 && scanStarts <= 4 && !cfg.forceGeneric
+    *kernelName = (verb == kScan || verb == kSearch) && scanStarts >= 1 && scanStarts <= 4 &&
+                          !cfg.forceGeneric
                       ? "k_scan_marked" : "k_generic";
   }
   switch (d.tableKind) {

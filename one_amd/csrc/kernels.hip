@@ -13,13 +13,14 @@
 //                whole 64-byte blocks, styles Last / Full of check / match, StatefulMatcher
 //                chunks; inline-asm byte step over a fused u8 table (<= 256 states), the hot-row
 //                table of a big DFA (sink + re-walk) or a class table of <= 64 KB in LDS.
-//   k_ragged.h   k_ragged<MODE, TABK>: the same walk over ragged lines (offsets[n+1]), the
-//                tail pad and the length-bucketing pre-pass.
+//   k_ragged.h   k_ragged<MODE, TABK>: the same walk over ragged lines (offsets[n+1]), lanes
+//                refilled from a workgroup cursor; the tail pad; k_generic's bucketing pre-pass.
 //   k_chunk.h    few long lines: chunks walked at once from guessed entry states, wrong guesses
 //                re-walked (speculative chunking).
 //   here         the lane functions (checkLane ... replaceLane: direct restatements of the
 //                reference's cores), k_generic<KIND, THREADS, VERB> and the list / rewrite
 //                kernels built on them (k_collect, k_matchall, k_replace, k_advance, k_visits),
+//                k_scan_marked (scan / search in two passes: mark candidate positions, visit them),
 //                k_fixed (strides that are not whole blocks, early-exit styles), line splitting,
 //                and launchBatch: which kernel runs what.
 // No MFMA anywhere: this is a gather workload bounded by the LDS gather rate and HBM streaming.

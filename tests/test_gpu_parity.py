@@ -211,6 +211,57 @@ def test_hot_row_tables_vs_oracle(rows):
             assert np.array_equal(e, vec[key + "end"])
 
 
+@pytest.mark.parametrize("name", ["err", "aab"])  # anchored: scan stays linear on the long line
+def test_marked_scan_and_search_vs_oracle(name):
+    """k_scan_marked (scan / search, DFAs with <= 4 start bytes): batches that must be halved to
+    fit the bitmap, a line longer than the bitmap covers (scanned the old way), empty lines,
+    candidates on the first / last byte of a line and straddling the 16-byte pieces, fixed
+    strides; every style, with and without the leader; against the oracle and against the
+    per-lane kernel (force_generic)."""
+    blob = load_dfa(name)
+    exe, gen, cpu = one_amd.Executable(blob), one_amd.Executable(blob, force_generic=True), O.CpuOracle(blob)
+    rng = np.random.default_rng(5)
+    plants = [b"error", b"aab", b"New York", b"eerror", b"aaab", b"erro", b"e", b"a"]
+    def text(total, seed):
+        d = W.alphabet_bytes(max(total, 1), seed)[:total].copy()
+        for k in range(0, max(total - 12, 0), 53):
+            pl = plants[(k // 53) % len(plants)]
+            d[k:k + len(pl)] = np.frombuffer(pl, dtype=np.uint8)
+        return d
+    shapes = [
+        list(rng.integers(0, 200, 3000)),
+        [1000] * 300,                                   # 256 lines x 1000 B > 64 KB: halved batches
+        [5] * 100 + [70000] + [0] * 50 + [17] * 100,    # one line beyond the bitmap
+        [0, 0, 0, 5, 0],
+        [16] * 700, [15] * 700, [1] * 900,
+    ]
+    for lens in shapes:
+        offsets = np.zeros(len(lens) + 1, dtype=np.uint64)
+        offsets[1:] = np.cumsum(lens)
+        data = text(int(offsets[-1]), len(lens))
+        for lead in (0, 1):
+            for si in range(1, 6):
+                exp = cpu.batch("scan", si, lead, data, offsets=offsets, threads=4)[0]
+                assert np.array_equal(one_amd.scan_batch(exe, data, si, lead, offsets=offsets), exp), \
+                    (name, "scan", si, lead, lens[:4])
+                assert np.array_equal(one_amd.scan_batch(gen, data, si, lead, offsets=offsets), exp)
+                er, es, ee = cpu.batch("search", si, lead, data, offsets=offsets, threads=4)
+                r, s, e = one_amd.search_batch(exe, data, si, lead, offsets=offsets)
+                assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee), \
+                    (name, "search", si, lead, lens[:4])
+    one_amd.scan_batch(exe, data, 1, 1, offsets=offsets)
+    assert one_amd.last_kernel() == "k_scan_marked"
+    for L, n in ((48, 2000), (64, 1500), (1000, 300)):
+        data = text(L * n, L)
+        for lead in (0, 1):
+            for si in (1, 4):
+                exp = cpu.batch("scan", si, lead, data, stride=L, n=n, threads=4)[0]
+                assert np.array_equal(one_amd.scan_batch(exe, data, si, lead, stride=L, n=n), exp)
+                er, es, ee = cpu.batch("search", si, lead, data, stride=L, n=n, threads=4)
+                r, s, e = one_amd.search_batch(exe, data, si, lead, stride=L, n=n)
+                assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee)
+
+
 @pytest.mark.parametrize("seed", [3, 4])
 def test_sparse_lds_tables_vs_oracle(seed):
     """REDGPU_TAB_LDS_SPARSE: a class table too big for LDS, mostly dead-state entries, packed in

@@ -68,7 +68,7 @@ def _widen(b: torch.Tensor, width: int, out_dtype) -> torch.Tensor:
     if width == 8:
         return b.contiguous().view(torch.int64).view(-1).to(out_dtype)
     if width == 1:
-        return b.contiguous().view(-1).to(out_dtype)
+        return b[:, 0].to(out_dtype)  # one strided kernel (no copy first): launches are what counts
     v = b.contiguous().view(_DT[width]).view(-1).to(torch.int64) & _MASK[width]
     return v.to(out_dtype)
 

@@ -716,8 +716,21 @@ k_scan_marked(DevDfa d, Batch b, int style, int lead) {
   const Tab<KIND> tab = stageTab<KIND, kThreads>(d, lds);
   uint16_t *marks16 = reinterpret_cast<uint16_t *>(lds + 512 + ((ldsTableBytes<KIND>(d) + 15) & ~size_t(15)));
   const uint32_t *marks32 = reinterpret_cast<const uint32_t *>(marks16);
+  // behind the bitmap: the batch's candidate list and per-line slots of the spread form below
+  uint32_t *cand = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(marks16) + kMarkBytes);
+  uint32_t *best = cand + kThreads;          // per line: lowest position whose attempt succeeded
+  uint32_t *lineLen = best + kThreads;
+  uint32_t *ran = lineLen + kThreads;        // per line: some attempt got past the leader
+  uint64_t *lineOff = reinterpret_cast<uint64_t *>(ran + kThreads);
+  uint32_t *candCount = reinterpret_cast<uint32_t *>(lineOff + kThreads);
   LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
             d.leaderLen};
+  // Attempts at different positions do not depend on one another except in scan with the leader
+  // (a partly matched leader consumes positions): everywhere else the batch's candidates are
+  // SPREAD over the threads, one each, instead of every lane visiting its own line's one after
+  // the other - a wave then runs visit() once, not once per candidate slot of its 64 lines.
+  const bool spread = kSearchVerb || !lead;
+  const int32_t initRes = c.resultOf(c.init);
   const uint32_t n2 = lead ? d.start2LeadCount : d.start2FreeCount;
   const StartFilter flt{lead ? d.startLeadWord : d.startFreeWord,
                         lead ? d.startLeadCount : d.startFreeCount,  // 1..4 (launchGeneric)
@@ -743,6 +756,7 @@ k_scan_marked(DevDfa d, Batch b, int style, int lead) {
     const uint64_t line = a + (threadIdx.x < cnt ? threadIdx.x : 0);
     const uint64_t o = lineStart(line);
     const uint64_t oEnd = b.offsets ? b.offsets[line + 1] : o + b.stride;
+    if (threadIdx.x == 0) *candCount = 0;
     if (!tooLong) {
       const uint64_t pieces = (dataAddr + last - baseAddr + 15) >> 4;
       // four pieces per thread and trip, requested together
@@ -774,9 +788,79 @@ k_scan_marked(DevDfa d, Batch b, int style, int lead) {
       }
     }
     __syncthreads();
-    if (threadIdx.x < cnt) {
-      const uint64_t n = b.offsets ? (oEnd - o >= b.stride ? oEnd - o - b.stride : 0)  // stride =
-                                   : b.stride;                    // trailing bytes to drop (ragged)
+    const uint64_t n = b.offsets ? (oEnd - o >= b.stride ? oEnd - o - b.stride : 0)  // stride =
+                                 : b.stride;                      // trailing bytes to drop (ragged)
+    bool spreadDone = false;
+    if (spread && !tooLong) {
+      // A: every line lists its marked positions
+      if (threadIdx.x < cnt) {
+        lineOff[threadIdx.x] = o;
+        lineLen[threadIdx.x] = uint32_t(n);
+        best[threadIdx.x] = 0xffffffffu;
+        ran[threadIdx.x] = 0;
+        const uint64_t bit0 = dataAddr + o - baseAddr;
+        for (uint64_t wd = bit0 >> 5; (wd << 5) < bit0 + n; ++wd) {
+          uint32_t m = marks32[wd];
+          const uint64_t wordBit = wd << 5;
+          if (wordBit < bit0) m &= ~0u << uint32_t(bit0 - wordBit);
+          if (wordBit + 32 > bit0 + n) m &= ~0u >> uint32_t(wordBit + 32 - (bit0 + n));
+          while (m) {
+            const uint32_t k = uint32_t(__builtin_ctz(m));
+            m &= m - 1;
+            const uint32_t at = atomicAdd(candCount, 1u);
+            if (at < uint32_t(kThreads)) cand[at] = (threadIdx.x << 16) | uint32_t(wordBit + k - bit0);
+          }
+        }
+      }
+      __syncthreads();
+      const uint32_t total = *candCount;
+      if (total <= uint32_t(kThreads)) {  // else: the lines visit their own (below)
+        spreadDone = true;
+        // B: one candidate per thread
+        bool found = false;
+        int32_t fr = 0;
+        uint64_t fs = 0, fe = 0;
+        uint32_t li = 0, at = 0;
+        if (threadIdx.x < total) {
+          const uint32_t entry = cand[threadIdx.x];
+          li = entry >> 16;
+          at = entry & 0xffffu;
+          const uint8_t *q = b.data + lineOff[li];
+          const uint64_t qn = lineLen[li];
+          typename std::conditional<kSearchVerb, SearchWalk<Tab<KIND>>, ScanWalk<Tab<KIND>>>::type
+              w(tab, c, q, qn, style, lead != 0);
+          w.skipped();
+          found = !w.visit(q[at], at, at + 1 < qn ? uint32_t(q[at + 1]) : kNoPeek);
+          if constexpr (kSearchVerb) {
+            fr = w.result; fs = w.matchStart; fe = w.matchEnd;
+          } else {
+            fr = w.ret;
+          }
+          if (found) atomicMin(&best[li], at);
+          else if (w.result != initRes) ran[li] = 1;
+        }
+        __syncthreads();
+        // C: the winner of each line reports; lines without one report "no match"
+        if (found && best[li] == at) {
+          b.result[a + li] = fr;
+          if (kSearchVerb) {
+            if (b.start) b.start[a + li] = fr != 0 ? fs : 0;
+            if (b.end) b.end[a + li] = fr != 0 ? fe : 0;
+          }
+        }
+        if (threadIdx.x < cnt && best[threadIdx.x] == 0xffffffffu) {
+          // what the sequential walk is left with: the initial state's result when no attempt
+          // ran (no byte, or - with the leader - no position past lookingAt), else 0
+          const int32_t r = n == 0 ? initRes : !lead ? 0 : ran[threadIdx.x] ? 0 : initRes;
+          b.result[line] = r;
+          if (kSearchVerb) {
+            if (b.start) b.start[line] = 0;
+            if (b.end) b.end[line] = 0;
+          }
+        }
+      }
+    }
+    if (!spreadDone && threadIdx.x < cnt) {
       const uint8_t *p = b.data + o;
       int32_t r;
       uint64_t st = 0, en = 0;
@@ -1518,7 +1602,9 @@ hipError_t launchGeneric(const DevDfa &d, const Batch &b, int verb, int style, i
   // scan / search over a DFA with at most 4 start bytes: mark the candidates, visit only those
   const uint32_t scanStarts = lead ? d.startLeadCount : d.startFreeCount;
   if ((verb == kScan || verb == kSearch) && scanStarts >= 1 && scanStarts <= 4 && !cfg.forceGeneric) {
-    const size_t markLds = 512 + ((ldsTableBytes<KIND>(d) + 15) & ~size_t(15)) + kMarkBytes;
+    // table, bitmap, candidate list + per-line slots (k_scan_marked's spread form)
+    const size_t markLds = 512 + ((ldsTableBytes<KIND>(d) + 15) & ~size_t(15)) + kMarkBytes +
+                           size_t(kScanThreads) * (4 * 4 + 8) + 16;
     if (markLds <= 158 * 1024) {
       hipError_t e_ = verb == kScan ? setLds(k_scan_marked<KIND, kScanThreads, kScan>, markLds)
                                     : setLds(k_scan_marked<KIND, kScanThreads, kSearch>, markLds);

@@ -722,15 +722,21 @@ k_scan_marked(DevDfa d, Batch b, int style, int lead) {
   uint32_t *lineLen = best + kThreads;
   uint32_t *ran = lineLen + kThreads;        // per line: some attempt got past the leader
   uint64_t *lineOff = reinterpret_cast<uint64_t *>(ran + kThreads);
-  uint32_t *candCount = reinterpret_cast<uint32_t *>(lineOff + kThreads);
+  uint32_t *candK = reinterpret_cast<uint32_t *>(lineOff + kThreads);  // scan with the leader
+  uint32_t *lineFirst = candK + kThreads;   // where a line's candidates start in the list
+  uint32_t *waveTot = lineFirst + kThreads;  // candidates per wave (block-wide prefix sum)
   LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
             d.leaderLen};
-  // Attempts at different positions do not depend on one another except in scan with the leader
-  // (a partly matched leader consumes positions): everywhere else the batch's candidates are
-  // SPREAD over the threads, one each, instead of every lane visiting its own line's one after
-  // the other - a wave then runs visit() once, not once per candidate slot of its 64 lines.
-  const bool spread = kSearchVerb || !lead;
+  // The batch's candidates are SPREAD over the threads, one each, instead of every lane visiting
+  // its own line's one after the other: a wave then runs visit() once, not once per candidate
+  // slot of its 64 lines.  Attempts at different positions do not depend on one another except
+  // in scan with the leader, where a partly matched leader consumes positions
+  // (Matcher.h:511-518): there the leader prefix length at every candidate is found in
+  // parallel first, each line then walks the "consumed" chain over its own candidates (no
+  // memory touched), and only the candidates still standing run their attempts.
+  const bool quirk = !kSearchVerb && lead != 0;
   const int32_t initRes = c.resultOf(c.init);
+  const uint32_t wave = threadIdx.x >> 6, laneId = threadIdx.x & 63u;
   const uint32_t n2 = lead ? d.start2LeadCount : d.start2FreeCount;
   const StartFilter flt{lead ? d.startLeadWord : d.startFreeWord,
                         lead ? d.startLeadCount : d.startFreeCount,  // 1..4 (launchGeneric)
@@ -756,7 +762,6 @@ k_scan_marked(DevDfa d, Batch b, int style, int lead) {
     const uint64_t line = a + (threadIdx.x < cnt ? threadIdx.x : 0);
     const uint64_t o = lineStart(line);
     const uint64_t oEnd = b.offsets ? b.offsets[line + 1] : o + b.stride;
-    if (threadIdx.x == 0) *candCount = 0;
     if (!tooLong) {
       const uint64_t pieces = (dataAddr + last - baseAddr + 15) >> 4;
       // four pieces per thread and trip, requested together
@@ -791,42 +796,92 @@ k_scan_marked(DevDfa d, Batch b, int style, int lead) {
     const uint64_t n = b.offsets ? (oEnd - o >= b.stride ? oEnd - o - b.stride : 0)  // stride =
                                  : b.stride;                      // trailing bytes to drop (ragged)
     bool spreadDone = false;
-    if (spread && !tooLong) {
-      // A: every line lists its marked positions
-      if (threadIdx.x < cnt) {
-        lineOff[threadIdx.x] = o;
-        lineLen[threadIdx.x] = uint32_t(n);
-        best[threadIdx.x] = 0xffffffffu;
-        ran[threadIdx.x] = 0;
-        const uint64_t bit0 = dataAddr + o - baseAddr;
-        for (uint64_t wd = bit0 >> 5; (wd << 5) < bit0 + n; ++wd) {
-          uint32_t m = marks32[wd];
-          const uint64_t wordBit = wd << 5;
-          if (wordBit < bit0) m &= ~0u << uint32_t(bit0 - wordBit);
-          if (wordBit + 32 > bit0 + n) m &= ~0u >> uint32_t(wordBit + 32 - (bit0 + n));
-          while (m) {
-            const uint32_t k = uint32_t(__builtin_ctz(m));
-            m &= m - 1;
-            const uint32_t at = atomicAdd(candCount, 1u);
-            if (at < uint32_t(kThreads)) cand[at] = (threadIdx.x << 16) | uint32_t(wordBit + k - bit0);
-          }
-        }
+    if (!tooLong) {
+      // A: every line counts its marked positions; a block-wide prefix sum gives each line its
+      // place in the batch's candidate list (position order within a line)
+      const uint64_t bit0 = dataAddr + o - baseAddr;
+      auto lineWord = [&](uint64_t wd) -> uint32_t {
+        uint32_t m = marks32[wd];
+        const uint64_t wordBit = wd << 5;
+        if (wordBit < bit0) m &= ~0u << uint32_t(bit0 - wordBit);
+        if (wordBit + 32 > bit0 + n) m &= ~0u >> uint32_t(wordBit + 32 - (bit0 + n));
+        return m;
+      };
+      uint32_t mine = 0;
+      if (threadIdx.x < cnt)
+        for (uint64_t wd = bit0 >> 5; (wd << 5) < bit0 + n; ++wd) mine += uint32_t(__builtin_popcount(lineWord(wd)));
+      uint32_t incl = mine;
+#pragma unroll
+      for (int sh = 1; sh < 64; sh <<= 1) {
+        const uint32_t up = uint32_t(__shfl_up(int(incl), sh, 64));
+        if (laneId >= uint32_t(sh)) incl += up;
       }
+      if (laneId == 63) waveTot[wave] = incl;
       __syncthreads();
-      const uint32_t total = *candCount;
+      uint32_t before = 0, total = 0;
+      for (uint32_t wv = 0; wv < uint32_t(kThreads / 64); ++wv) {
+        if (wv < wave) before += waveTot[wv];
+        total += waveTot[wv];
+      }
       if (total <= uint32_t(kThreads)) {  // else: the lines visit their own (below)
         spreadDone = true;
+        const uint32_t firstAt = before + incl - mine;
+        if (threadIdx.x < cnt) {
+          lineOff[threadIdx.x] = o;
+          lineLen[threadIdx.x] = uint32_t(n);
+          lineFirst[threadIdx.x] = firstAt;
+          best[threadIdx.x] = 0xffffffffu;
+          ran[threadIdx.x] = 0;
+          uint32_t at = firstAt;
+          for (uint64_t wd = bit0 >> 5; (wd << 5) < bit0 + n; ++wd) {
+            uint32_t m = lineWord(wd);
+            while (m) {
+              const uint32_t k = uint32_t(__builtin_ctz(m));
+              m &= m - 1;
+              cand[at++] = (threadIdx.x << 16) | uint32_t((wd << 5) + k - bit0);
+            }
+          }
+        }
+        __syncthreads();
         // B: one candidate per thread
-        bool found = false;
-        int32_t fr = 0;
-        uint64_t fs = 0, fe = 0;
         uint32_t li = 0, at = 0;
-        if (threadIdx.x < total) {
+        const uint8_t *q = b.data;
+        uint64_t qn = 0;
+        bool go = threadIdx.x < total;
+        if (go) {
           const uint32_t entry = cand[threadIdx.x];
           li = entry >> 16;
           at = entry & 0xffffu;
-          const uint8_t *q = b.data + lineOff[li];
-          const uint64_t qn = lineLen[li];
+          q = b.data + lineOff[li];
+          qn = lineLen[li];
+        }
+        if (quirk) {
+          // B1: how much of the leader matches here; B2: which candidates an earlier one's
+          // partly (or wholly) matched leader has consumed
+          if (go) {
+            uint32_t kk = 0;
+            while (kk < c.leaderLen && at + kk < qn && c.leader[kk] == c.eq[q[at + kk]]) ++kk;
+            candK[threadIdx.x] = kk;
+          }
+          __syncthreads();
+          if (threadIdx.x < cnt) {
+            uint64_t resume = 0;
+            for (uint32_t r = 0; r < mine; ++r) {
+              const uint32_t ci = lineFirst[threadIdx.x] + r;
+              const uint64_t i = cand[ci] & 0xffffu;
+              const uint32_t kk = candK[ci];
+              if (i < resume) { candK[ci] = 0xffffffffu; continue; }   // consumed: never visited
+              resume = i + kk + 1;  // on the mismatching byte (or past the leader), then ++in
+              if (kk != c.leaderLen) candK[ci] = 0xffffffffu;         // visited, no attempt
+            }
+          }
+          __syncthreads();
+          if (go && candK[threadIdx.x] == 0xffffffffu) go = false;
+        }
+        bool found = false;
+        int32_t fr = 0;
+        uint64_t fs = 0, fe = 0;
+        if (go) {
           typename std::conditional<kSearchVerb, SearchWalk<Tab<KIND>>, ScanWalk<Tab<KIND>>>::type
               w(tab, c, q, qn, style, lead != 0);
           w.skipped();
@@ -850,7 +905,7 @@ k_scan_marked(DevDfa d, Batch b, int style, int lead) {
         }
         if (threadIdx.x < cnt && best[threadIdx.x] == 0xffffffffu) {
           // what the sequential walk is left with: the initial state's result when no attempt
-          // ran (no byte, or - with the leader - no position past lookingAt), else 0
+          // ran (no byte, or - with the leader - no position past it), else 0
           const int32_t r = n == 0 ? initRes : !lead ? 0 : ran[threadIdx.x] ? 0 : initRes;
           b.result[line] = r;
           if (kSearchVerb) {
@@ -1604,7 +1659,7 @@ hipError_t launchGeneric(const DevDfa &d, const Batch &b, int verb, int style, i
   if ((verb == kScan || verb == kSearch) && scanStarts >= 1 && scanStarts <= 4 && !cfg.forceGeneric) {
     // table, bitmap, candidate list + per-line slots (k_scan_marked's spread form)
     const size_t markLds = 512 + ((ldsTableBytes<KIND>(d) + 15) & ~size_t(15)) + kMarkBytes +
-                           size_t(kScanThreads) * (4 * 4 + 8) + 16;
+                           size_t(kScanThreads) * (6 * 4 + 8) + 32;
     if (markLds <= 158 * 1024) {
       hipError_t e_ = verb == kScan ? setLds(k_scan_marked<KIND, kScanThreads, kScan>, markLds)
                                     : setLds(k_scan_marked<KIND, kScanThreads, kSearch>, markLds);

@@ -67,6 +67,9 @@ typedef struct redgpu_opts {
                                      early_death (tests, tuning) */
 #define REDGPU_F_NO_CHUNKING  32u /* never cut long lines into speculatively walked chunks */
 #define REDGPU_F_FORCE_CHUNKING 64u /* ... or always, whatever the DFA looks like (tests) */
+#define REDGPU_F_STREAM_CHAINS_2 128u /* fixed-stride hot path: always the two-chain kernel ... */
+#define REDGPU_F_STREAM_CHAINS_4 256u /* ... or always the four-chain one, whatever the batch size
+                                         (default: by batch size; tests, tuning) */
 #define REDGPU_F_FORCE_HOT     4u /* a table too big for LDS always gets hot rows in LDS, even
                                      when the visit model finds no locality (tests, tuning) */
 

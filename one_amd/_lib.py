@@ -13,6 +13,7 @@ OK, EAPI, EEXEC, ELIMIT, EHIP = 0, -1, -2, -3, -5
 DEVICE_CURRENT, DEVICE_NONE = -1, -2
 F_FORCE_GENERIC, F_FORCE_GLOBAL, F_FORCE_HOT, F_NO_BUCKETING, F_FORCE_STREAM = 1, 2, 4, 8, 16
 F_NO_CHUNKING, F_FORCE_CHUNKING = 32, 64
+F_STREAM_CHAINS_2, F_STREAM_CHAINS_4 = 128, 256
 
 
 class Opts(C.Structure):

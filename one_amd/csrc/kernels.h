@@ -62,6 +62,8 @@ struct LaunchCfg {
   int forceStream = 0;  // whole-line kernels even for early-death DFAs (REDGPU_F_FORCE_STREAM)
   int noChunking = 0;   // never cut long lines into speculative chunks (REDGPU_F_NO_CHUNKING)
   int forceChunking = 0; // ... or whenever the shape allows, whatever the DFA (REDGPU_F_FORCE_CHUNKING)
+  int streamChains = 0;  // fixed-stride hot path: 0 = by batch size, 2 = k_stream.h always,
+                         // 3 / 4 = k_stream4.hip always (REDGPU_F_STREAM_CHAINS_*; tests, tuning)
 };
 
 // Launches the kernel for (verb, style, doLeader) on `stream`; returns hipSuccess or the
@@ -107,6 +109,12 @@ hipError_t launchSplitLines(const uint8_t *data, uint64_t len, uint8_t delim, ui
 // bench.py's read-bandwidth calibration: one streaming pass over `bytes` (16-byte aligned).
 hipError_t launchDiagRead(const void *data, uint64_t bytes, uint32_t *sink, int numCUs,
                           hipStream_t stream);
+
+// k_stream4.hip: the fixed-stride hot path with 3-4 chains per lane (mode = k_stream.h's
+// StreamMode value: Last+start+end 0, Last+end 1, Full+start 3, Full 4).
+bool stream4Eligible(const DevDfa &dfa, const Batch &b, const LaunchCfg &cfg);
+hipError_t launchStream4(int mode, const DevDfa &dfa, const Batch &b, const LaunchCfg &cfg,
+                         hipStream_t stream);
 
 // True when the specialised fixed-stride kernels can run this DFA at all.
 bool fastPathEligible(const DevDfa &dfa);

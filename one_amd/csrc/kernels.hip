@@ -2068,6 +2068,13 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
     hipError_t e;
     Batch sb = b;
     if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
+    if (stream4Eligible(d, sb, cfg)) {
+      const int mode = style == kStyLast ? (sb.start ? kSmLastStartEnd : kSmLastEnd)
+                                         : (sb.start ? kSmFullStart : kSmFull);
+      *kernelName = style == kStyLast ? (sb.start ? "k_stream4<last,start,end>" : "k_stream4<last,end>")
+                                      : (sb.start ? "k_stream4<full,start>" : "k_stream4<full>");
+      e = launchStream4(mode, d, sb, cfg, stream);
+    } else
     if (style == kStyLast) {
       if (sb.start) { *kernelName = "k_stream<last,start,end>"; e = launchStreamT<kSmLastStartEnd>(d, sb, cfg, stream); }
       else { *kernelName = "k_stream<last,end>"; e = launchStreamT<kSmLastEnd>(d, sb, cfg, stream); }

@@ -116,7 +116,9 @@ int runDev(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint8
                 (dfa->flags & REDGPU_F_NO_BUCKETING) ? 1 : 0,
                 (dfa->flags & REDGPU_F_FORCE_STREAM) ? 1 : 0,
                 (dfa->flags & REDGPU_F_NO_CHUNKING) ? 1 : 0,
-                (dfa->flags & REDGPU_F_FORCE_CHUNKING) ? 1 : 0};
+                (dfa->flags & REDGPU_F_FORCE_CHUNKING) ? 1 : 0,
+                (dfa->flags & REDGPU_F_STREAM_CHAINS_2) ? 2
+                : (dfa->flags & REDGPU_F_STREAM_CHAINS_4) ? 4 : 0};
   const char *name = "";
   hipError_t e = launchBatch(dfa->im->dev, b, verb, style, doLeader ? 1 : 0, cfg, stream, &name);
   tlsKernel = name;

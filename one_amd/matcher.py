@@ -78,7 +78,7 @@ class Executable:
     def __init__(self, serialized: bytes, device=None, *, force_generic=False,
                  force_global=False, force_hot=False, no_bucketing=False,
                  force_stream=False, no_chunking=False, force_chunking=False,
-                 lds_table_max=0):
+                 lds_table_max=0, stream_chains=0):
         if serialized is None or len(serialized) == 0:
             raise RedExceptApi("serialized dfa string_view is empty")  # Executable.cpp:66
         o = _lib.Opts()
@@ -91,7 +91,9 @@ class Executable:
                   (_lib.F_NO_BUCKETING if no_bucketing else 0) | \
                   (_lib.F_FORCE_STREAM if force_stream else 0) | \
                   (_lib.F_NO_CHUNKING if no_chunking else 0) | \
-                  (_lib.F_FORCE_CHUNKING if force_chunking else 0)
+                  (_lib.F_FORCE_CHUNKING if force_chunking else 0) | \
+                  (_lib.F_STREAM_CHAINS_2 if stream_chains == 2 else 0) | \
+                  (_lib.F_STREAM_CHAINS_4 if stream_chains == 4 else 0)
         self._h = C.c_void_p()
         blob = bytes(serialized)
         _check(_lib.lib().redgpu_dfa_create(blob, len(blob), C.byref(o), C.byref(self._h)))

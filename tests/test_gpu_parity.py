@@ -138,6 +138,34 @@ def test_fixed_stride_hot_path_vs_oracle(name, stride, n):
         assert one_amd.last_kernel().startswith("k_fixed"), one_amd.last_kernel()
 
 
+@pytest.mark.parametrize("chains", [2, 4])
+@pytest.mark.parametrize("stride,n", [(64, 1), (64, 255), (64, 257), (64, 256 * 8 * 3 + 65),
+                                      (128, 3000), (4096, 700), (64, 70001)])
+@pytest.mark.parametrize("name", ["syn256", "uri", "err", "dotstar_err"])
+def test_stream_kernels_two_and_four_chains_vs_oracle(name, stride, n, chains):
+    """k_stream (2 lines per lane) and k_stream4 (4 lines per lane, wave-tiles handed out by an
+    LDS ticket) forced onto batches of any size: styles Last / Full of match and check, with and
+    without start, with the leader; tile counts that leave waves without work and tiles cut by
+    the end of the batch (Matcher.h:363-495)."""
+    blob = load_dfa(name)
+    exe = one_amd.Executable(blob, force_stream=True, stream_chains=chains, no_chunking=True)
+    cpu = O.CpuOracle(blob)
+    data = _fixed_inputs(name, n, stride, seed=3 * stride + n)
+    for si in (4, 5):
+        for lead in (0, 1):
+            er, es, ee = cpu.batch("match", si, lead, data, stride=stride, n=n, threads=4)
+            r, s, e = one_amd.match_batch(exe, data, si, lead, stride=stride, n=n)
+            k = one_amd.last_kernel()
+            assert k.startswith("k_stream4<" if chains == 4 else "k_stream<"), k
+            assert np.array_equal(r, er), (name, si, lead, k)
+            assert np.array_equal(s, es) and np.array_equal(e, ee), (name, si, lead, k)
+            r2, _, e2 = one_amd.match_batch(exe, data, si, lead, stride=stride, n=n,
+                                            want_start=False)
+            assert np.array_equal(r2, er) and np.array_equal(e2, ee)
+            cr, _, _ = cpu.batch("check", si, 0, data, stride=stride, n=n, threads=4)
+            assert np.array_equal(one_amd.check_batch(exe, data, si, 0, stride=stride, n=n), cr)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_dfas_vs_oracle(seed):
     """Synthetic DFAs of every table placement (incl. reachable pure dead ends) vs the oracle."""

@@ -38,6 +38,7 @@ extern "C" {
 #define REDGPU_EEXEC  (-2) /* unsupported format / style    (RedExceptExec)  */
 #define REDGPU_ELIMIT (-3) /* capacity exceeded             (RedExceptLimit) */
 #define REDGPU_EHIP   (-5) /* HIP runtime / device failure  (new)            */
+#define REDGPU_ERCCL  (-6) /* RCCL unavailable or failed    (new, groups)    */
 
 /* include/Matcher.h:67-74 */
 #define REDGPU_STY_INSTANT 1
@@ -294,6 +295,75 @@ int redgpu_split_lines_dev(const redgpu_dfa *dfa, const uint8_t *data, uint64_t 
  * increment (it keeps the loads alive); its value carries no meaning. */
 int redgpu_diag_read_dev(const redgpu_dfa *dfa, const void *data, uint64_t bytes, uint32_t *sink,
                          void *stream);
+
+/* More calibration kernels behind bench.py's roofline block (device-resident, asynchronous):
+ *  - redgpu_diag_lds_dev: the walk without its memory side - `rounds` x 64 dependent table
+ *    lookups per chain, 4 chains per lane, 512 lanes per CU, input bytes from registers; times
+ *    the LDS gather rate that bounds a one-lookup-per-byte walk.  *lookups (host) receives the
+ *    number of lookups the launch performs.
+ *  - redgpu_diag_walked_dev: adds to *walked (device uint64, zeroed by the caller) the bytes the
+ *    loop of match<styLast,doLeader> (include/Matcher.h:424-479) consumes over the batch: the
+ *    bytes an early-exit walk actually reads, as opposed to the bytes of the lines. */
+int redgpu_diag_lds_dev(const redgpu_dfa *dfa, uint32_t rounds, uint32_t *sink, uint64_t *lookups,
+                        void *stream);
+int redgpu_diag_walked_dev(const redgpu_dfa *dfa, int do_leader, const uint8_t *data,
+                           const uint64_t *offsets, uint64_t stride, uint64_t n, uint64_t *walked,
+                           void *stream);
+
+/* The host-buffer entry points stage through device buffers and two private streams that each
+ * HOST THREAD keeps per device (no allocation, stream creation or device-wide synchronisation per
+ * call).  They are released when the thread exits; a long-lived thread that is done with the
+ * library may release them early.  redgpu_scratch_entries: device scratch buffers the launches
+ * currently cache process-wide (bounded; diagnostics / tests). */
+void redgpu_thread_release(void);
+uint64_t redgpu_scratch_entries(void);
+
+/* ---- several GPUs of one node --------------------------------------------------------------
+ * The reference scales by calling its read-only matcher from N threads over one shared Red
+ * (tools/thr_red.cpp:84-91).  The device form of that picture: a GROUP holds one image of the
+ * same blob per device ("uploaded once" per GPU); a batch is cut into contiguous shards - equal
+ * line counts for a fixed stride, equal BYTES for ragged lines - every device scans its shard
+ * with no data-path exchange, and only the per-line results travel.
+ *   redgpu_group_create      devices[] may name a device more than once (the shards then share
+ *                            that GPU: how a one-GPU box rehearses the sharding); opts->device
+ *                            is ignored.  Fails as redgpu_dfa_create does.
+ *   redgpu_group_plan        cuts[0..n_devices]: shard g = lines [cuts[g], cuts[g+1]).
+ *   redgpu_group_batch       HOST buffers, verb = REDGPU_VERB_*: one host thread per device runs
+ *                            its shard through the host-buffer entry point of that verb; results
+ *                            land in the caller's arrays (start / end NULL for check and scan).
+ *   redgpu_group_batch_dev   shard g already resident on device g (data[g], offsets[g] or NULL,
+ *                            n[g] lines; ragged offsets are relative to data[g]).  Every device
+ *                            scans on a stream of its own; results are packed into compact
+ *                            records (result in 1/2/4 bytes by the DFA's largest result, start /
+ *                            end in 1/2/4/8 bytes by the longest possible position), moved to the
+ *                            ROOT device (devices[0]) over xGMI - REDGPU_GATHER_PEER: peer copies,
+ *                            REDGPU_GATHER_RCCL: ncclSend / ncclRecv (librccl.so loaded on first
+ *                            use) - and widened there into result / start / end (memory of the
+ *                            root device, sum(n[]) entries, shard order).  Asynchronous: the
+ *                            results are complete when `root_stream` (a stream of the root device,
+ *                            NULL = its null stream) has reached this point.  One such call at a
+ *                            time per group (serialised internally). */
+typedef struct redgpu_group redgpu_group;
+#define REDGPU_VERB_CHECK  0
+#define REDGPU_VERB_MATCH  1
+#define REDGPU_VERB_SCAN   2
+#define REDGPU_VERB_SEARCH 3
+#define REDGPU_GATHER_PEER 0
+#define REDGPU_GATHER_RCCL 1
+int redgpu_group_create(const void *reda, size_t len, const redgpu_opts *opts,
+                        const int32_t *devices, uint32_t n_devices, redgpu_group **out);
+void redgpu_group_destroy(redgpu_group *group);
+uint32_t redgpu_group_size(const redgpu_group *group);
+const redgpu_dfa *redgpu_group_member(const redgpu_group *group, uint32_t i);
+int redgpu_group_plan(const redgpu_group *group, const uint64_t *offsets, uint64_t stride,
+                      uint64_t n, uint64_t *cuts);
+int redgpu_group_batch(const redgpu_group *group, int verb, int style, int do_leader,
+                       const uint8_t *data, const uint64_t *offsets, uint64_t stride, uint64_t n,
+                       int32_t *result, uint64_t *start, uint64_t *end);
+int redgpu_group_batch_dev(redgpu_group *group, int verb, int style, int do_leader,
+                           const uint8_t *const *data, const uint64_t *const *offsets,
+                           uint64_t stride, const uint64_t *n, int32_t *result, uint64_t *start,
+                           uint64_t *end, int gather, void *root_stream);
 
 /* Name of the kernel the last *_batch* call on this thread launched (for profiles), or "". */
 const char *redgpu_last_kernel(void);

@@ -6,14 +6,14 @@ Only the hot path lives here: `csrc/` (gfx950 HIP kernels + the C-ABI of include
 (synthetic inputs of the BASELINE configs).  Importing the package does not load the HIP
 extension; the first call does, and fails loudly if it is not built.
 """
-from .matcher import (Executable, Style, RedExcept, RedExceptApi, RedExceptExec,  # noqa: F401
+from .matcher import (Executable, Group, Style, RedExcept, RedExceptApi, RedExceptExec,  # noqa: F401
                       RedExceptLimit, RedExceptHip, check, check_batch, check_header, match,
                       match_batch, scan, scan_batch, search, search_batch, collect,
                       collect_batch, match_all, match_all_batch, advance_batch,
                       StatefulMatcher, STATE_INITIAL, split_lines, replace, replace_batch, last_kernel, styInstant, styFirst,
                       styTangent, styLast, styFull)
 
-__all__ = ["Executable", "Style", "check", "match", "scan", "check_batch", "match_batch",
+__all__ = ["Executable", "Group", "Style", "check", "match", "scan", "check_batch", "match_batch",
            "scan_batch", "search", "search_batch", "collect", "collect_batch", "check_header",
            "match_all", "match_all_batch", "advance_batch", "StatefulMatcher", "STATE_INITIAL",
            "split_lines", "replace", "replace_batch", "last_kernel"]

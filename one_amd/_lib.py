@@ -9,7 +9,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libredgpu.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "redgpu.h")
 
-OK, EAPI, EEXEC, ELIMIT, EHIP = 0, -1, -2, -3, -5
+OK, EAPI, EEXEC, ELIMIT, EHIP, ERCCL = 0, -1, -2, -3, -5, -6
+VERB_CHECK, VERB_MATCH, VERB_SCAN, VERB_SEARCH = 0, 1, 2, 3
+GATHER_PEER, GATHER_RCCL = 0, 1
 DEVICE_CURRENT, DEVICE_NONE = -1, -2
 F_FORCE_GENERIC, F_FORCE_GLOBAL, F_FORCE_HOT, F_NO_BUCKETING, F_FORCE_STREAM = 1, 2, 4, 8, 16
 F_NO_CHUNKING, F_FORCE_CHUNKING = 32, 64
@@ -133,6 +135,28 @@ def lib() -> C.CDLL:
         l.redgpu_split_lines_dev.argtypes = [vp, vp, u64, C.c_uint8, vp, u64, vp, vp]
         l.redgpu_diag_read_dev.restype = C.c_int
         l.redgpu_diag_read_dev.argtypes = [vp, vp, u64, vp, vp]
+        l.redgpu_diag_lds_dev.restype = C.c_int
+        l.redgpu_diag_lds_dev.argtypes = [vp, C.c_uint32, vp, C.POINTER(u64), vp]
+        l.redgpu_diag_walked_dev.restype = C.c_int
+        l.redgpu_diag_walked_dev.argtypes = [vp, i32, vp, vp, u64, u64, vp, vp]
+        l.redgpu_thread_release.restype = None
+        l.redgpu_scratch_entries.restype = u64
+        l.redgpu_group_create.restype = C.c_int
+        l.redgpu_group_create.argtypes = [vp, C.c_size_t, C.POINTER(Opts), C.POINTER(C.c_int32),
+                                          C.c_uint32, C.POINTER(vp)]
+        l.redgpu_group_destroy.restype = None
+        l.redgpu_group_destroy.argtypes = [vp]
+        l.redgpu_group_size.restype = C.c_uint32
+        l.redgpu_group_size.argtypes = [vp]
+        l.redgpu_group_member.restype = vp
+        l.redgpu_group_member.argtypes = [vp, C.c_uint32]
+        l.redgpu_group_plan.restype = C.c_int
+        l.redgpu_group_plan.argtypes = [vp, vp, u64, u64, vp]
+        l.redgpu_group_batch.restype = C.c_int
+        l.redgpu_group_batch.argtypes = [vp, i32, i32, i32, vp, vp, u64, u64, vp, vp, vp]
+        l.redgpu_group_batch_dev.restype = C.c_int
+        l.redgpu_group_batch_dev.argtypes = [vp, i32, i32, i32, vp, vp, u64, vp, vp, vp, vp, i32,
+                                             vp]
         _lib = l
     return _lib
 

@@ -1,0 +1,57 @@
+// host_stage.h - what the HOST-buffer entry points of include/redgpu.h stage through.
+//
+// The reference's matchers take caller memory and touch nothing else
+// (/root/reference/quol/red/doc/Performance.md:81-84: read-only, lock-free, re-entrant; N threads
+// over one Executable in tools/thr_red.cpp:84-91).  A device needs staging, so each host thread
+// keeps, per device it has used: two private non-blocking streams and a small set of grow-only
+// device buffers.  Nothing is allocated or freed per call once the buffers have reached the
+// thread's batch size (round 1 paid five hipMalloc + five hipFree - each hipFree a device-wide
+// synchronisation that stalled every other thread's streams - and a stream create/destroy per
+// call).  The cache dies with its thread (thread_local destructor) or on redgpu_thread_release().
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+#include <hip/hip_runtime.h>
+
+namespace redgpu {
+
+class HostStage {
+ public:
+  static constexpr int kBufs = 14;
+  int device = -1;
+  hipStream_t streams[2] = {nullptr, nullptr};
+  hipEvent_t ready = nullptr;  // "the shared uploads (offsets, replacement) have landed"
+
+  // grow-only device buffer `slot` of at least `bytes` (+16: 16-byte loads of a last line never
+  // leave the allocation).  Growing waits for this thread's own streams, then frees and allocates.
+  hipError_t get(int slot, size_t bytes, void **out);
+  hipError_t sync();  // both streams
+  void release();
+  ~HostStage() { release(); }
+
+ private:
+  struct Buf {
+    void *p = nullptr;
+    size_t cap = 0;
+  } bufs_[kBufs];
+  friend hipError_t hostStage(int, HostStage **);
+};
+
+// The calling thread's stage for `device` (created on first use; the device must be current).
+hipError_t hostStage(int device, HostStage **out);
+// Frees every stage the calling thread holds.
+void hostStageReleaseThread();
+
+// Pins caller memory for the duration of one call so that copies on two streams overlap
+// (H2D of one chunk beside D2H of the previous one); silently does nothing if the runtime
+// refuses the range (read-only mappings, already registered memory).
+struct ScopedPin {
+  void *p = nullptr;
+  ScopedPin(const void *ptr, size_t bytes, bool enable);
+  ~ScopedPin();
+  bool pinned() const { return p != nullptr; }
+};
+
+}  // namespace redgpu

@@ -722,47 +722,12 @@ k_bucket_scatter(const uint64_t *offsets, uint64_t n, uint64_t trim, uint64_t pe
 
 constexpr uint64_t kBucketMinLines = 16384;
 
-// Scratch for the ragged launch (tail pad, permutation, histograms), cached per host thread and
-// (device, stream): work queued on one stream runs in order, so the next call on that stream may
-// reuse the buffer the previous one used; another stream or another thread gets its own.
+// Scratch for the ragged launch (tail pad, permutation, histograms): the process-wide pool of
+// host_stage.cpp, keyed by (device, stream) - work queued on one stream runs in order, so the next
+// call on that stream may reuse the buffer the previous one used; another stream gets its own.
 // hipMallocAsync/hipFreeAsync per call cost ~12 us of host time and a bubble on the stream.
-// A buffer is only released (hipFree: synchronising) when it has to grow or its slot is
-// recycled; at thread exit it is left to the runtime's teardown.
-struct RaggedScratch {
-  int dev = -1;
-  hipStream_t stream = nullptr;
-  void *ptr = nullptr;
-  size_t bytes = 0;
-};
-
 inline hipError_t raggedScratch(hipStream_t stream, size_t bytes, void **out) {
-  constexpr int kSlots = 4;
-  thread_local RaggedScratch slots[kSlots];
-  thread_local int victim = 0;
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return e;
-  RaggedScratch *slot = nullptr;
-  for (auto &sl : slots)
-    if (sl.ptr && sl.dev == dev && sl.stream == stream) slot = &sl;
-  if (slot && slot->bytes >= bytes) { *out = slot->ptr; return hipSuccess; }
-  if (!slot) {
-    for (auto &sl : slots)
-      if (!sl.ptr) { slot = &sl; break; }
-    if (!slot) { slot = &slots[victim]; victim = (victim + 1) % kSlots; }
-  }
-  if (slot->ptr) {
-    (void)hipFree(slot->ptr);  // waits for the work that may still be using it
-    slot->ptr = nullptr;
-  }
-  const size_t want = bytes + bytes / 2 + 4096;
-  e = hipMalloc(&slot->ptr, want);
-  if (e != hipSuccess) { slot->ptr = nullptr; return e; }
-  slot->dev = dev;
-  slot->stream = stream;
-  slot->bytes = want;
-  *out = slot->ptr;
-  return hipSuccess;
+  return scratchFor(stream, bytes, out);
 }
 
 // pad[0..192) = data[padStart, total) followed by zeros (see the header comment)

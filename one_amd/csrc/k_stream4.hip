@@ -323,6 +323,51 @@ k_stream4(DevDfa d, Batch io) {
   }
 }
 
+// ---- LDS gather calibration (bench.py: roofline.lds_roof) -----------------------------------
+// The walk without its memory side: the DFA's 64 KB table in LDS (pseudo-random bytes when the
+// DFA's primary table is not a fused u8 one), 4 chains per lane, 8 waves per CU, the 4-chain
+// lookup-only step above (counted waits), input bytes from 16 registers per chain filled by a
+// hash of (lane, chain, workgroup) - uniformly random bytes, as configs[1] feeds the real walk.
+__global__ void __launch_bounds__(kS4Threads)
+k_diag_lds(DevDfa d, uint32_t rounds, uint32_t *sink) {
+  __shared__ __align__(16) uint8_t lds[kS4Tab];
+  const bool real = d.tableKind == 1 && d.tableBytes == kS4Tab;
+  for (uint32_t i = threadIdx.x; i < kS4Tab / 16; i += kS4Threads) {
+    uint4 v;
+    if (real) {
+      v = reinterpret_cast<const uint4 *>(d.table)[i];
+    } else {
+      uint64_t z = (uint64_t(i) + 1) * 0x9E3779B97F4A7C15ull;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      z ^= z >> 31;
+      v = make_uint4(uint32_t(z), uint32_t(z >> 32), uint32_t(z * 3), uint32_t((z * 5) >> 32));
+    }
+    reinterpret_cast<uint4 *>(lds)[i] = v;
+  }
+  asm volatile("" : : "v"(lds) : "memory");
+  __syncthreads();
+  uint32_t w[16][4];
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      uint64_t z = (uint64_t(blockIdx.x) * kS4Threads + threadIdx.x) * 64 + k * 4 + c + 1;
+      z *= 0x9E3779B97F4A7C15ull;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      w[k][c] = uint32_t(z ^ (z >> 31));
+    }
+  uint32_t s[4] = {d.init & 0xffu, (d.init + 1) & 0xffu, (d.init + 2) & 0xffu, (d.init + 3) & 0xffu};
+  Book4 b[4];
+  uint64_t was[4];
+  for (uint32_t r = 0; r < rounds; ++r) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) stepDword<kM4Full, 4, 0>(s, w[k], b, was, 0u, 0u);
+  }
+  if ((s[0] ^ s[1] ^ s[2] ^ s[3]) == 0x12345u) atomicAdd(sink, 1u);  // keeps the walk alive
+}
+
 template <int MODE, int C>
 hipError_t launchS4(const DevDfa &d, const Batch &b, const LaunchCfg &cfg, hipStream_t stream) {
   const uint64_t tiles = (b.n + 64 * C - 1) / (64 * C);
@@ -372,6 +417,14 @@ bool stream4Eligible(const DevDfa &d, const Batch &b, const LaunchCfg &cfg) {
          d.tableBytes <= kS4Tab &&
          (cfg.streamChains >= 3 || tiles >= uint64_t(cfg.numCUs) * (kS4Threads / 64)) &&
          tiles / uint64_t(cfg.numCUs) < (1ull << 31);
+}
+
+hipError_t launchDiagLds(const DevDfa &d, uint32_t rounds, uint32_t *sink, int numCUs,
+                         hipStream_t stream, uint64_t *lookups) {
+  hipLaunchKernelGGL(k_diag_lds, dim3(uint32_t(numCUs)), dim3(kS4Threads), 0, stream, d, rounds,
+                     sink);
+  if (lookups) *lookups = uint64_t(numCUs) * kS4Threads * 4 * 64 * rounds;
+  return hipGetLastError();
 }
 
 hipError_t launchStream4(int mode, const DevDfa &d, const Batch &b, const LaunchCfg &cfg,

@@ -116,6 +116,22 @@ bool stream4Eligible(const DevDfa &dfa, const Batch &b, const LaunchCfg &cfg);
 hipError_t launchStream4(int mode, const DevDfa &dfa, const Batch &b, const LaunchCfg &cfg,
                          hipStream_t stream);
 
+// Device scratch for the launches that need some (host_stage.cpp): a process-wide pool keyed by
+// (current device, stream), bounded, entries of a library-owned stream dropped with the stream.
+hipError_t scratchFor(hipStream_t stream, size_t bytes, void **out);
+void scratchDrop(int device, hipStream_t stream);
+size_t scratchEntries();
+
+// bench.py's calibrations.  launchDiagLds: `rounds` x 64 dependent table lookups per chain, 4
+// chains per lane, 512 lanes per CU, bytes from registers (no input traffic): the LDS gather
+// roof of the one-lookup-per-byte walk; *lookups receives the number issued.
+// launchWalked: *walked (device u64, zeroed by the caller) += the bytes match<styLast,lead>'s loop
+// (include/Matcher.h:443-479) consumes per line - what an early-exit walk actually reads.
+hipError_t launchDiagLds(const DevDfa &dfa, uint32_t rounds, uint32_t *sink, int numCUs,
+                         hipStream_t stream, uint64_t *lookups);
+hipError_t launchWalked(const DevDfa &dfa, const Batch &b, int doLeader, unsigned long long *walked,
+                        const LaunchCfg &cfg, hipStream_t stream);
+
 // True when the specialised fixed-stride kernels can run this DFA at all.
 bool fastPathEligible(const DevDfa &dfa);
 

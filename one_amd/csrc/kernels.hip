@@ -1490,6 +1490,46 @@ k_visits(DevDfa d, Batch b, uint32_t *hist) {
   }
 }
 
+// bench.py's "bytes actually walked": what the loop of match<styLast,lead> (include/Matcher.h:
+// 424-479) consumes per line - nothing when the leader peek fails, else every byte up to and
+// including the one that reaches a pure dead end.  One atomic per wave.
+template <int KIND, int kThreads>
+__global__ void __launch_bounds__(kThreads)
+k_walked(DevDfa d, Batch b, int lead, unsigned long long *walked) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const Tab<KIND> tab = stageTab<KIND, kThreads>(d, lds);
+  LaneCtx c;
+  c.eq = lds;
+  c.leader = lds + 256;
+  c.res = d.result;
+  c.init = d.init; c.leaderNext = d.leaderNext; c.nPureDead = d.nPureDead;
+  c.firstAccept = d.firstAccept; c.leaderLen = d.leaderLen;
+  const uint64_t step = uint64_t(gridDim.x) * kThreads;
+  unsigned long long mine = 0;
+  for (uint64_t line = uint64_t(blockIdx.x) * kThreads + threadIdx.x; line < b.n; line += step) {
+    const uint8_t *p;
+    uint64_t n;
+    if (b.offsets) {
+      const uint64_t o = b.offsets[line];
+      p = b.data + o;
+      n = b.offsets[line + 1] - o;
+      n = n >= b.stride ? n - b.stride : 0;
+    } else {
+      p = b.data + line * b.stride;
+      n = b.stride;
+    }
+    if (lead && !lookingAt(c, p, 0, n)) continue;
+    uint32_t s = d.init;
+    walkBytes(p, 0, n, [&](uint32_t byte, uint64_t) {
+      s = tab.next(s, byte);
+      ++mine;
+      return s >= d.nPureDead;
+    });
+  }
+  for (int o = 32; o; o >>= 1) mine += __shfl_xor(mine, o);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(walked, mine);
+}
+
 // ---- line splitting on the device ------------------------------------
 // The rule is sampleLines' (lib/Util.cpp:109-130): a line is [start, position of the delimiter),
 // the next one starts after the delimiter, and bytes after the last delimiter are not a line.
@@ -1952,6 +1992,33 @@ hipError_t launchDiagRead(const void *data, uint64_t bytes, uint32_t *sink, int 
   hipLaunchKernelGGL(k_diag_read, dim3(uint32_t(numCUs) * 8), dim3(256), 0, stream,
                      static_cast<const uint4 *>(data), bytes / 16, sink);
   return hipGetLastError();
+}
+
+template <int KIND>
+hipError_t launchWalkedK(const DevDfa &d, const Batch &b, int lead, unsigned long long *walked,
+                         const LaunchCfg &cfg, hipStream_t stream) {
+  constexpr bool kLds = Tab<KIND>::kInLds || KIND == REDGPU_TAB_HOT_ROWS;
+  constexpr int kThreads = kLds ? 1024 : 256;
+  const size_t ldsBytes = 512 + ldsTableBytes<KIND>(d);
+  hipError_t e = setLds(k_walked<KIND, kThreads>, ldsBytes);
+  if (e != hipSuccess) return e;
+  uint64_t blocks = (b.n + kThreads - 1) / kThreads;
+  const uint64_t perCu = kLds ? (ldsBytes <= 80 * 1024 ? 2 : 1) : 8;
+  const uint64_t capBlocks = uint64_t(cfg.numCUs) * perCu;
+  if (blocks > capBlocks) blocks = capBlocks;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL((k_walked<KIND, kThreads>), dim3(uint32_t(blocks)), dim3(kThreads), ldsBytes,
+                     stream, d, b, lead, walked);
+  return hipGetLastError();
+}
+
+hipError_t launchWalked(const DevDfa &d, const Batch &b, int doLeader, unsigned long long *walked,
+                        const LaunchCfg &cfg, hipStream_t stream) {
+  if (b.n == 0) return hipSuccess;
+  const int lead = doLeader && d.leaderLen > 0;
+#define WK_CALL(K) launchWalkedK<K>(d, b, lead, walked, cfg, stream)
+  REDGPU_KIND_SWITCH(WK_CALL)
+#undef WK_CALL
 }
 
 hipError_t launchVisits(const DevDfa &d, const Batch &b, uint32_t *hist, const LaunchCfg &cfg,

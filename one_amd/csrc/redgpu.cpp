@@ -15,81 +15,13 @@
 #include <hip/hip_runtime.h>
 
 #include "dfa_image.h"
+#include "host_stage.h"
 #include "kernels.h"
+#include "redgpu_internal.h"
 
 using namespace redgpu;
 
-// What is expensive to make - the validated blob copy, the repacked image and its device
-// allocations - is immutable once built and shared between handles created from the same blob
-// with the same options on the same device (the loader cache below).
-struct SharedImage {
-  std::vector<uint8_t> blob;  // our own copy (Executable(gCopyTag,..) semantics)
-  DfaImage img;
-  int device = REDGPU_DEVICE_NONE;
-  uint32_t buildFlags = 0;    // the flags / LDS budget the image was built with (cache key)
-  uint32_t ldsTableMax = 0;
-  void *dTable = nullptr;
-  void *dResult = nullptr;
-  void *dEquivLeader = nullptr;
-  DevDfa dev{};
-  ~SharedImage();
-};
-
-SharedImage::~SharedImage() {
-  if (device < 0) return;
-  int prev = -1;
-  const bool sw = hipGetDevice(&prev) == hipSuccess && prev != device &&
-                  hipSetDevice(device) == hipSuccess;
-  if (dTable) (void)hipFree(dTable);
-  if (dResult) (void)hipFree(dResult);
-  if (dEquivLeader) (void)hipFree(dEquivLeader);
-  if (sw) (void)hipSetDevice(prev);
-}
-
-struct redgpu_dfa {
-  std::shared_ptr<SharedImage> im;
-  int numCUs = 0;
-  uint32_t flags = 0;
-  uint32_t ldsTableMax = 0;
-};
-
 namespace {
-
-thread_local std::string tlsError;
-thread_local const char *tlsKernel = "";
-
-int fail(int code, const std::string &msg) {
-  tlsError = msg;
-  return code;
-}
-
-int failHip(hipError_t e, const char *what) {
-  tlsError = std::string(what) + ": " + hipGetErrorString(e);
-  return REDGPU_EHIP;
-}
-
-#define HIP_TRY(expr, what)                          \
-  do {                                               \
-    hipError_t e_ = (expr);                          \
-    if (e_ != hipSuccess) return failHip(e_, what);  \
-  } while (0)
-
-// RAII: run on the handle's device, restore the caller's current device afterwards
-struct DeviceScope {
-  int prev = -1;
-  bool switched = false;
-  hipError_t err = hipSuccess;
-  explicit DeviceScope(int dev) {
-    err = hipGetDevice(&prev);
-    if (err == hipSuccess && prev != dev) {
-      err = hipSetDevice(dev);
-      switched = (err == hipSuccess);
-    }
-  }
-  ~DeviceScope() {
-    if (switched) (void)hipSetDevice(prev);
-  }
-};
 
 int checkStyle(int style) {
   if (style < REDGPU_STY_INSTANT || style > REDGPU_STY_FULL)
@@ -126,7 +58,51 @@ int runDev(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint8
   return REDGPU_OK;
 }
 
-// host-buffer form: stage through device memory on a private stream
+// offsets[0..n] of a host-buffer call: monotone (a decreasing pair would underflow a line length
+// on the device and send the walk far outside the buffer)
+int checkOffsets(const uint64_t *offsets, uint64_t n) {
+  for (uint64_t i = 0; i < n; ++i)
+    if (offsets[i] > offsets[i + 1]) return fail(REDGPU_EAPI, "offsets not monotonic");
+  return REDGPU_OK;
+}
+
+// The calling thread's staging for the handle's device (host_stage.h); the device scope must
+// be held by the caller.
+int stageOf(const redgpu_dfa *dfa, HostStage **st) {
+  hipError_t e = hostStage(dfa->im->device, st);
+  if (e != hipSuccess) return failHip(e, "host staging (streams)");
+  return REDGPU_OK;
+}
+
+#define STAGE_TRY(expr, what)                                  \
+  do {                                                         \
+    hipError_t e_ = (expr);                                    \
+    if (e_ != hipSuccess) {                                    \
+      (void)st->sync();                                        \
+      return failHip(e_, what);                                \
+    }                                                          \
+  } while (0)
+
+// device buffer slots of a HostStage
+enum StageSlot : int {
+  kSlData = 0,   // +parity
+  kSlRes = 2,    // +parity
+  kSlStart = 4,  // +parity
+  kSlEnd = 6,    // +parity
+  kSlOff = 8,
+  kSlAux0 = 9,   // counts / state / replacement ...
+  kSlAux1 = 10,
+  kSlAux2 = 11,
+  kSlAux3 = 12,
+};
+
+constexpr uint64_t kHostChunkBytes = 32ull << 20;
+
+// host-buffer form: the batch is cut into chunks of ~32 MiB of input that alternate between the
+// thread's two private streams - copy in, kernel, copy out per chunk - so that with pinned
+// caller memory (registered for the duration of the call when the batch has several chunks)
+// the upload of one chunk runs beside the download of the previous one.  No allocation, no
+// stream creation and no device-wide synchronisation per call (host_stage.h).
 int runHost(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint8_t *data,
             const uint64_t *offsets, uint64_t stride, uint64_t n, int32_t *result,
             uint64_t *start, uint64_t *end) {
@@ -135,56 +111,100 @@ int runHost(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint
   if (int rc = checkStyle(style)) return rc;
   if (n == 0) return REDGPU_OK;
   if (!result) return fail(REDGPU_EAPI, "null result buffer");
-  uint64_t total = offsets ? offsets[n] : stride * n;
-  if (offsets) {
-    for (uint64_t i = 0; i < n; ++i)
-      if (offsets[i] > offsets[i + 1]) return fail(REDGPU_EAPI, "offsets not monotonic");
-  }
+  if (!offsets && stride >= (1ull << 40)) return fail(REDGPU_ELIMIT, "stride too large");
+  if (offsets)
+    if (int rc = checkOffsets(offsets, n)) return rc;
+  const uint64_t total = offsets ? offsets[n] : stride * n;
   if (total && !data) return fail(REDGPU_EAPI, "null data buffer");
   DeviceScope scope(dfa->im->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  HostStage *st = nullptr;
+  if (int rc = stageOf(dfa, &st)) return rc;
 
-  hipStream_t s = nullptr;
-  uint8_t *dData = nullptr;
-  uint64_t *dOff = nullptr, *dStart = nullptr, *dEnd = nullptr;
-  int32_t *dRes = nullptr;
-  int rc = REDGPU_OK;
-  auto cleanup = [&]() {
-    if (dData) (void)hipFree(dData);
-    if (dOff) (void)hipFree(dOff);
-    if (dRes) (void)hipFree(dRes);
-    if (dStart) (void)hipFree(dStart);
-    if (dEnd) (void)hipFree(dEnd);
-    if (s) (void)hipStreamDestroy(s);
-  };
-#define HOST_TRY(expr, what)                                         \
-  do {                                                               \
-    hipError_t e_ = (expr);                                          \
-    if (e_ != hipSuccess) { rc = failHip(e_, what); cleanup(); return rc; } \
-  } while (0)
-  HOST_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
-  // +16 so that 16-byte loads of the last line never leave the allocation
-  HOST_TRY(hipMalloc(reinterpret_cast<void **>(&dData), total + 16), "hipMalloc data");
-  HOST_TRY(hipMalloc(reinterpret_cast<void **>(&dRes), n * sizeof(int32_t)), "hipMalloc result");
-  if (offsets) {
-    HOST_TRY(hipMalloc(reinterpret_cast<void **>(&dOff), (n + 1) * sizeof(uint64_t)),
-             "hipMalloc offsets");
-    HOST_TRY(hipMemcpyAsync(dOff, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s),
-             "copy offsets");
+  // chunk plan: cuts[c] .. cuts[c + 1] are the lines of chunk c
+  std::vector<uint64_t> cuts{0};
+  const uint64_t base0 = offsets ? offsets[0] : 0;
+  if (total - base0 > 2 * kHostChunkBytes && n >= 4096) {
+    if (!offsets) {
+      uint64_t per = (kHostChunkBytes / (stride ? stride : 1)) & ~uint64_t(1023);
+      if (per < 1024) per = 1024;
+      for (uint64_t lo = per; lo < n; lo += per) cuts.push_back(lo);
+    } else {
+      uint64_t lo = 0;
+      while (lo < n) {
+        // first line whose start is >= kHostChunkBytes past this chunk's start
+        const uint64_t target = offsets[lo] + kHostChunkBytes;
+        uint64_t a = lo + 1, b = n;
+        while (a < b) {
+          const uint64_t mid = (a + b) / 2;
+          if (offsets[mid] >= target) b = mid; else a = mid + 1;
+        }
+        lo = a;
+        if (lo < n) cuts.push_back(lo);
+      }
+    }
   }
-  if (start) HOST_TRY(hipMalloc(reinterpret_cast<void **>(&dStart), n * 8), "hipMalloc start");
-  if (end) HOST_TRY(hipMalloc(reinterpret_cast<void **>(&dEnd), n * 8), "hipMalloc end");
-  if (total)
-    HOST_TRY(hipMemcpyAsync(dData, data, total, hipMemcpyHostToDevice, s), "copy data");
-  rc = runDev(dfa, verb, style, doLeader, dData, dOff, stride, n, dRes, dStart, dEnd, s);
-  if (rc != REDGPU_OK) { cleanup(); return rc; }
-  HOST_TRY(hipMemcpyAsync(result, dRes, n * sizeof(int32_t), hipMemcpyDeviceToHost, s),
-           "copy result");
-  if (start) HOST_TRY(hipMemcpyAsync(start, dStart, n * 8, hipMemcpyDeviceToHost, s), "copy start");
-  if (end) HOST_TRY(hipMemcpyAsync(end, dEnd, n * 8, hipMemcpyDeviceToHost, s), "copy end");
-  HOST_TRY(hipStreamSynchronize(s), "hipStreamSynchronize");
-#undef HOST_TRY
-  cleanup();
+  cuts.push_back(n);
+  const size_t nChunks = cuts.size() - 1;
+  const bool multi = nChunks > 1;
+  uint64_t maxBytes = 0, maxLines = 0;
+  for (size_t c = 0; c < nChunks; ++c) {
+    const uint64_t lo = cuts[c], hi = cuts[c + 1];
+    const uint64_t bytes = offsets ? offsets[hi] - offsets[lo] : (hi - lo) * stride;
+    if (bytes > maxBytes) maxBytes = bytes;
+    if (hi - lo > maxLines) maxLines = hi - lo;
+  }
+  // every buffer before the first copy: growing one waits for the streams
+  uint8_t *dData[2] = {nullptr, nullptr};
+  int32_t *dRes[2] = {nullptr, nullptr};
+  uint64_t *dStart[2] = {nullptr, nullptr}, *dEnd[2] = {nullptr, nullptr}, *dOff = nullptr;
+  for (int k = 0; k < (multi ? 2 : 1); ++k) {
+    STAGE_TRY(st->get(kSlData + k, maxBytes, reinterpret_cast<void **>(&dData[k])), "hipMalloc data");
+    STAGE_TRY(st->get(kSlRes + k, maxLines * 4, reinterpret_cast<void **>(&dRes[k])), "hipMalloc result");
+    if (start)
+      STAGE_TRY(st->get(kSlStart + k, maxLines * 8, reinterpret_cast<void **>(&dStart[k])), "hipMalloc start");
+    if (end)
+      STAGE_TRY(st->get(kSlEnd + k, maxLines * 8, reinterpret_cast<void **>(&dEnd[k])), "hipMalloc end");
+  }
+  if (offsets)
+    STAGE_TRY(st->get(kSlOff, (n + 1) * 8, reinterpret_cast<void **>(&dOff)), "hipMalloc offsets");
+
+  // pinned caller memory makes the copies truly asynchronous (only worth its price when there
+  // is something to overlap)
+  ScopedPin pinIn(data, total, multi), pinRes(result, n * 4, multi),
+      pinStart(start, start ? n * 8 : 0, multi), pinEnd(end, end ? n * 8 : 0, multi);
+
+  if (offsets) {
+    STAGE_TRY(hipMemcpyAsync(dOff, offsets, (n + 1) * 8, hipMemcpyHostToDevice, st->streams[0]),
+              "copy offsets");
+    if (multi) {
+      STAGE_TRY(hipEventRecord(st->ready, st->streams[0]), "hipEventRecord");
+      STAGE_TRY(hipStreamWaitEvent(st->streams[1], st->ready, 0), "hipStreamWaitEvent");
+    }
+  }
+  for (size_t c = 0; c < nChunks; ++c) {
+    const int k = int(c & 1);
+    hipStream_t s = st->streams[k];
+    const uint64_t lo = cuts[c], hi = cuts[c + 1], nl = hi - lo;
+    const uint64_t byteLo = offsets ? offsets[lo] : lo * stride;
+    const uint64_t bytes = offsets ? offsets[hi] - byteLo : nl * stride;
+    if (bytes)
+      STAGE_TRY(hipMemcpyAsync(dData[k], data + byteLo, bytes, hipMemcpyHostToDevice, s), "copy data");
+    // ragged: absolute offsets against a base shifted back by the chunk's first byte
+    const uint8_t *base = offsets ? dData[k] - byteLo : dData[k];
+    const int rc = runDev(dfa, verb, style, doLeader, base, offsets ? dOff + lo : nullptr, stride,
+                          nl, dRes[k], dStart[k], dEnd[k], s);
+    if (rc != REDGPU_OK) {
+      (void)st->sync();
+      return rc;
+    }
+    STAGE_TRY(hipMemcpyAsync(result + lo, dRes[k], nl * 4, hipMemcpyDeviceToHost, s), "copy result");
+    if (start)
+      STAGE_TRY(hipMemcpyAsync(start + lo, dStart[k], nl * 8, hipMemcpyDeviceToHost, s), "copy start");
+    if (end)
+      STAGE_TRY(hipMemcpyAsync(end + lo, dEnd[k], nl * 8, hipMemcpyDeviceToHost, s), "copy end");
+  }
+  STAGE_TRY(st->sync(), "hipStreamSynchronize");
   return REDGPU_OK;
 }
 
@@ -499,45 +519,46 @@ static int listHost(const redgpu_dfa *dfa, int listVerb, const uint8_t *data,
   if (dfa->im->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
   if (n == 0) return REDGPU_OK;
   if (!counts) return fail(REDGPU_EAPI, "null counts buffer");
+  if (cap && !result) return fail(REDGPU_EAPI, "null result buffer");
+  if (offsets)
+    if (int rc = checkOffsets(offsets, n)) return rc;
+  if (!offsets && stride >= (1ull << 40)) return fail(REDGPU_ELIMIT, "stride too large");
+  if (cap && n > (~0ull / 16) / cap) return fail(REDGPU_ELIMIT, "n * cap too large");
   const uint64_t total = offsets ? offsets[n] : stride * n;
   if (total && !data) return fail(REDGPU_EAPI, "null data buffer");
   DeviceScope scope(dfa->im->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  HostStage *st = nullptr;
+  if (int rc = stageOf(dfa, &st)) return rc;
+  hipStream_t s = st->streams[0];
   uint8_t *dData = nullptr;
   uint64_t *dOff = nullptr, *dCnt = nullptr, *dStart = nullptr, *dEnd = nullptr;
   int32_t *dRes = nullptr;
-  auto cleanup = [&]() {
-    for (void *q : {(void *)dData, (void *)dOff, (void *)dCnt, (void *)dRes, (void *)dStart, (void *)dEnd})
-      if (q) (void)hipFree(q);
-  };
-  int rc = REDGPU_OK;
-#define CH_TRY(expr, what)                                                    \
-  do {                                                                        \
-    hipError_t e_ = (expr);                                                   \
-    if (e_ != hipSuccess) { rc = failHip(e_, what); cleanup(); return rc; }   \
-  } while (0)
   const uint64_t slots = n * cap;
-  CH_TRY(hipMalloc(reinterpret_cast<void **>(&dData), total + 16), "hipMalloc data");
-  CH_TRY(hipMalloc(reinterpret_cast<void **>(&dCnt), n * 8), "hipMalloc counts");
-  CH_TRY(hipMalloc(reinterpret_cast<void **>(&dRes), (slots + 1) * 4), "hipMalloc result");
-  if (start) CH_TRY(hipMalloc(reinterpret_cast<void **>(&dStart), (slots + 1) * 8), "hipMalloc start");
-  if (end) CH_TRY(hipMalloc(reinterpret_cast<void **>(&dEnd), (slots + 1) * 8), "hipMalloc end");
+  STAGE_TRY(st->get(kSlData, total, reinterpret_cast<void **>(&dData)), "hipMalloc data");
+  STAGE_TRY(st->get(kSlAux0, n * 8, reinterpret_cast<void **>(&dCnt)), "hipMalloc counts");
+  STAGE_TRY(st->get(kSlRes, (slots + 1) * 4, reinterpret_cast<void **>(&dRes)), "hipMalloc result");
+  if (start)
+    STAGE_TRY(st->get(kSlStart, (slots + 1) * 8, reinterpret_cast<void **>(&dStart)), "hipMalloc start");
+  if (end)
+    STAGE_TRY(st->get(kSlEnd, (slots + 1) * 8, reinterpret_cast<void **>(&dEnd)), "hipMalloc end");
   if (offsets) {
-    CH_TRY(hipMalloc(reinterpret_cast<void **>(&dOff), (n + 1) * 8), "hipMalloc offsets");
-    CH_TRY(hipMemcpy(dOff, offsets, (n + 1) * 8, hipMemcpyHostToDevice), "copy offsets");
+    STAGE_TRY(st->get(kSlOff, (n + 1) * 8, reinterpret_cast<void **>(&dOff)), "hipMalloc offsets");
+    STAGE_TRY(hipMemcpyAsync(dOff, offsets, (n + 1) * 8, hipMemcpyHostToDevice, s), "copy offsets");
   }
-  if (total) CH_TRY(hipMemcpy(dData, data, total, hipMemcpyHostToDevice), "copy data");
-  rc = collectDev(dfa, listVerb, dData, dOff, stride, n, cap, dCnt, dRes, dStart, dEnd, nullptr);
-  if (rc != REDGPU_OK) { cleanup(); return rc; }
-  CH_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
-  CH_TRY(hipMemcpy(counts, dCnt, n * 8, hipMemcpyDeviceToHost), "copy counts");
+  if (total) STAGE_TRY(hipMemcpyAsync(dData, data, total, hipMemcpyHostToDevice, s), "copy data");
+  const int rc = collectDev(dfa, listVerb, dData, dOff, stride, n, cap, dCnt, dRes, dStart, dEnd, s);
+  if (rc != REDGPU_OK) {
+    (void)st->sync();
+    return rc;
+  }
+  STAGE_TRY(hipMemcpyAsync(counts, dCnt, n * 8, hipMemcpyDeviceToHost, s), "copy counts");
   if (slots) {
-    CH_TRY(hipMemcpy(result, dRes, slots * 4, hipMemcpyDeviceToHost), "copy result");
-    if (start) CH_TRY(hipMemcpy(start, dStart, slots * 8, hipMemcpyDeviceToHost), "copy start");
-    if (end) CH_TRY(hipMemcpy(end, dEnd, slots * 8, hipMemcpyDeviceToHost), "copy end");
+    STAGE_TRY(hipMemcpyAsync(result, dRes, slots * 4, hipMemcpyDeviceToHost, s), "copy result");
+    if (start) STAGE_TRY(hipMemcpyAsync(start, dStart, slots * 8, hipMemcpyDeviceToHost, s), "copy start");
+    if (end) STAGE_TRY(hipMemcpyAsync(end, dEnd, slots * 8, hipMemcpyDeviceToHost, s), "copy end");
   }
-#undef CH_TRY
-  cleanup();
+  STAGE_TRY(hipStreamSynchronize(s), "hipStreamSynchronize");
   return REDGPU_OK;
 }
 
@@ -576,45 +597,42 @@ int redgpu_replace_batch(const redgpu_dfa *dfa, int style, int do_leader, const 
   if (int rc = checkStyle(style)) return rc;
   if (n == 0) return REDGPU_OK;
   if (!counts || !out_offsets) return fail(REDGPU_EAPI, "null output buffer");
+  if (offsets)
+    if (int rc = checkOffsets(offsets, n)) return rc;
+  if (!offsets && stride >= (1ull << 40)) return fail(REDGPU_ELIMIT, "stride too large");
   const uint64_t total = offsets ? offsets[n] : stride * n;
-  if (offsets) {
-    for (uint64_t i = 0; i < n; ++i)
-      if (offsets[i] > offsets[i + 1]) return fail(REDGPU_EAPI, "offsets not monotonic");
-  }
   if (total && !data) return fail(REDGPU_EAPI, "null data buffer");
   if (repl_len && !repl) return fail(REDGPU_EAPI, "null replacement");
   DeviceScope scope(dfa->im->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  HostStage *st = nullptr;
+  if (int rc = stageOf(dfa, &st)) return rc;
+  hipStream_t s = st->streams[0];
   uint8_t *dData = nullptr, *dRepl = nullptr, *dOut = nullptr;
   uint64_t *dOff = nullptr, *dCnt = nullptr, *dOutOff = nullptr;
-  auto cleanup = [&]() {
-    for (void *q : {(void *)dData, (void *)dRepl, (void *)dOut, (void *)dOff, (void *)dCnt,
-                    (void *)dOutOff})
-      if (q) (void)hipFree(q);
-  };
-  int rc = REDGPU_OK;
-#define RP_TRY(expr, what)                                                    \
-  do {                                                                        \
-    hipError_t e_ = (expr);                                                   \
-    if (e_ != hipSuccess) { rc = failHip(e_, what); cleanup(); return rc; }   \
-  } while (0)
-  RP_TRY(hipMalloc(reinterpret_cast<void **>(&dData), total + 16), "hipMalloc data");
-  RP_TRY(hipMalloc(reinterpret_cast<void **>(&dRepl), repl_len + 16), "hipMalloc repl");
-  RP_TRY(hipMalloc(reinterpret_cast<void **>(&dCnt), n * 8), "hipMalloc counts");
-  RP_TRY(hipMalloc(reinterpret_cast<void **>(&dOutOff), (n + 1) * 8), "hipMalloc out offsets");
-  if (out && out_cap) RP_TRY(hipMalloc(reinterpret_cast<void **>(&dOut), out_cap), "hipMalloc out");
+  STAGE_TRY(st->get(kSlData, total, reinterpret_cast<void **>(&dData)), "hipMalloc data");
+  STAGE_TRY(st->get(kSlAux0, repl_len, reinterpret_cast<void **>(&dRepl)), "hipMalloc repl");
+  STAGE_TRY(st->get(kSlAux1, n * 8, reinterpret_cast<void **>(&dCnt)), "hipMalloc counts");
+  STAGE_TRY(st->get(kSlAux2, (n + 1) * 8, reinterpret_cast<void **>(&dOutOff)), "hipMalloc out offsets");
+  if (out && out_cap)
+    STAGE_TRY(st->get(kSlAux3, out_cap, reinterpret_cast<void **>(&dOut)), "hipMalloc out");
   if (offsets) {
-    RP_TRY(hipMalloc(reinterpret_cast<void **>(&dOff), (n + 1) * 8), "hipMalloc offsets");
-    RP_TRY(hipMemcpy(dOff, offsets, (n + 1) * 8, hipMemcpyHostToDevice), "copy offsets");
+    STAGE_TRY(st->get(kSlOff, (n + 1) * 8, reinterpret_cast<void **>(&dOff)), "hipMalloc offsets");
+    STAGE_TRY(hipMemcpyAsync(dOff, offsets, (n + 1) * 8, hipMemcpyHostToDevice, s), "copy offsets");
   }
-  if (total) RP_TRY(hipMemcpy(dData, data, total, hipMemcpyHostToDevice), "copy data");
-  if (repl_len) RP_TRY(hipMemcpy(dRepl, repl, repl_len, hipMemcpyHostToDevice), "copy repl");
-  rc = redgpu_replace_batch_dev(dfa, style, do_leader, dData, dOff, stride, n, dRepl, repl_len,
-                                max_count, dCnt, dOutOff, dOut, dOut ? out_cap : 0, nullptr);
-  if (rc != REDGPU_OK) { cleanup(); return rc; }
-  RP_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
-  RP_TRY(hipMemcpy(counts, dCnt, n * 8, hipMemcpyDeviceToHost), "copy counts");
-  RP_TRY(hipMemcpy(out_offsets, dOutOff, (n + 1) * 8, hipMemcpyDeviceToHost), "copy out offsets");
+  if (total) STAGE_TRY(hipMemcpyAsync(dData, data, total, hipMemcpyHostToDevice, s), "copy data");
+  if (repl_len) STAGE_TRY(hipMemcpyAsync(dRepl, repl, repl_len, hipMemcpyHostToDevice, s), "copy repl");
+  const int rc = redgpu_replace_batch_dev(dfa, style, do_leader, dData, dOff, stride, n, dRepl,
+                                          repl_len, max_count, dCnt, dOutOff, dOut,
+                                          dOut ? out_cap : 0, s);
+  if (rc != REDGPU_OK) {
+    (void)st->sync();
+    return rc;
+  }
+  STAGE_TRY(hipMemcpyAsync(counts, dCnt, n * 8, hipMemcpyDeviceToHost, s), "copy counts");
+  STAGE_TRY(hipMemcpyAsync(out_offsets, dOutOff, (n + 1) * 8, hipMemcpyDeviceToHost, s),
+            "copy out offsets");
+  STAGE_TRY(hipStreamSynchronize(s), "hipStreamSynchronize");
   if (dOut) {
     // the lines that fit are a prefix (offsets are monotone): copy up to the last one that does
     uint64_t lo = 0, hi = n;  // largest k with out_offsets[k] <= out_cap
@@ -622,11 +640,11 @@ int redgpu_replace_batch(const redgpu_dfa *dfa, int style, int do_leader, const 
       const uint64_t mid = (lo + hi + 1) / 2;
       if (out_offsets[mid] <= out_cap) lo = mid; else hi = mid - 1;
     }
-    if (out_offsets[lo])
-      RP_TRY(hipMemcpy(out, dOut, out_offsets[lo], hipMemcpyDeviceToHost), "copy out");
+    if (out_offsets[lo]) {
+      STAGE_TRY(hipMemcpyAsync(out, dOut, out_offsets[lo], hipMemcpyDeviceToHost, s), "copy out");
+      STAGE_TRY(hipStreamSynchronize(s), "hipStreamSynchronize");
+    }
   }
-#undef RP_TRY
-  cleanup();
   return REDGPU_OK;
 }
 
@@ -663,39 +681,34 @@ int redgpu_split_lines(const redgpu_dfa *dfa, const uint8_t *data, uint64_t len,
   if (len && !data) return fail(REDGPU_EAPI, "null data buffer");
   DeviceScope scope(dfa->im->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  HostStage *st = nullptr;
+  if (int rc = stageOf(dfa, &st)) return rc;
+  hipStream_t s = st->streams[0];
   uint8_t *dData = nullptr;
   uint64_t *dOff = nullptr, *dN = nullptr;
-  auto cleanup = [&]() {
-    for (void *q : {(void *)dData, (void *)dOff, (void *)dN})
-      if (q) (void)hipFree(q);
-  };
-  int rc = REDGPU_OK;
-#define SP_TRY(expr, what)                                                    \
-  do {                                                                        \
-    hipError_t e_ = (expr);                                                   \
-    if (e_ != hipSuccess) { rc = failHip(e_, what); cleanup(); return rc; }   \
-  } while (0)
-  SP_TRY(hipMalloc(reinterpret_cast<void **>(&dData), len + 16), "hipMalloc data");
-  SP_TRY(hipMalloc(reinterpret_cast<void **>(&dN), 8), "hipMalloc count");
-  if (len) SP_TRY(hipMemcpy(dData, data, len, hipMemcpyHostToDevice), "copy data");
+  STAGE_TRY(st->get(kSlData, len, reinterpret_cast<void **>(&dData)), "hipMalloc data");
+  STAGE_TRY(st->get(kSlAux0, 8, reinterpret_cast<void **>(&dN)), "hipMalloc count");
   // count first (room for no line at all), then size the device offsets to what will be kept
-  SP_TRY(hipMalloc(reinterpret_cast<void **>(&dOff), 8), "hipMalloc offsets");
-  rc = redgpu_split_lines_dev(dfa, dData, len, delim, dOff, 0, dN, nullptr);
-  if (rc != REDGPU_OK) { cleanup(); return rc; }
-  SP_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
-  SP_TRY(hipMemcpy(n_lines, dN, 8, hipMemcpyDeviceToHost), "copy count");
+  STAGE_TRY(st->get(kSlOff, 8, reinterpret_cast<void **>(&dOff)), "hipMalloc offsets");
+  if (len) STAGE_TRY(hipMemcpyAsync(dData, data, len, hipMemcpyHostToDevice, s), "copy data");
+  int rc = redgpu_split_lines_dev(dfa, dData, len, delim, dOff, 0, dN, s);
+  if (rc != REDGPU_OK) {
+    (void)st->sync();
+    return rc;
+  }
+  STAGE_TRY(hipMemcpyAsync(n_lines, dN, 8, hipMemcpyDeviceToHost, s), "copy count");
+  STAGE_TRY(hipStreamSynchronize(s), "hipStreamSynchronize");
   const uint64_t got = *n_lines < cap ? *n_lines : cap;
   if (got) {
-    (void)hipFree(dOff);
-    dOff = nullptr;
-    SP_TRY(hipMalloc(reinterpret_cast<void **>(&dOff), (got + 1) * 8), "hipMalloc offsets");
-    rc = redgpu_split_lines_dev(dfa, dData, len, delim, dOff, got, dN, nullptr);
-    if (rc != REDGPU_OK) { cleanup(); return rc; }
-    SP_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    STAGE_TRY(st->get(kSlOff, (got + 1) * 8, reinterpret_cast<void **>(&dOff)), "hipMalloc offsets");
+    rc = redgpu_split_lines_dev(dfa, dData, len, delim, dOff, got, dN, s);
+    if (rc != REDGPU_OK) {
+      (void)st->sync();
+      return rc;
+    }
   }
-  SP_TRY(hipMemcpy(offsets, dOff, (got + 1) * 8, hipMemcpyDeviceToHost), "copy offsets");
-#undef SP_TRY
-  cleanup();
+  STAGE_TRY(hipMemcpyAsync(offsets, dOff, (got + 1) * 8, hipMemcpyDeviceToHost, s), "copy offsets");
+  STAGE_TRY(hipStreamSynchronize(s), "hipStreamSynchronize");
   return REDGPU_OK;
 }
 
@@ -712,6 +725,46 @@ int redgpu_diag_read_dev(const redgpu_dfa *dfa, const void *data, uint64_t bytes
   if (e != hipSuccess) return failHip(e, "kernel launch");
   return REDGPU_OK;
 }
+
+int redgpu_diag_lds_dev(const redgpu_dfa *dfa, uint32_t rounds, uint32_t *sink, uint64_t *lookups,
+                        void *stream) {
+  if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
+  if (dfa->im->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (!sink) return fail(REDGPU_EAPI, "null buffer");
+  DeviceScope scope(dfa->im->device);
+  if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  hipError_t e = launchDiagLds(dfa->im->dev, rounds, sink, dfa->numCUs,
+                               static_cast<hipStream_t>(stream), lookups);
+  tlsKernel = "k_diag_lds";
+  if (e != hipSuccess) return failHip(e, "kernel launch");
+  return REDGPU_OK;
+}
+
+int redgpu_diag_walked_dev(const redgpu_dfa *dfa, int do_leader, const uint8_t *data,
+                           const uint64_t *offsets, uint64_t stride, uint64_t n, uint64_t *walked,
+                           void *stream) {
+  if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
+  if (dfa->im->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (n == 0) return REDGPU_OK;
+  if (!walked) return fail(REDGPU_EAPI, "null buffer");
+  if (!data && (offsets || stride)) return fail(REDGPU_EAPI, "null data buffer");
+  if (offsets && stride > 16) return fail(REDGPU_EAPI, "with offsets, stride is the number of "
+                                                       "trailing bytes to drop per line (0..16)");
+  DeviceScope scope(dfa->im->device);
+  if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  Batch b{data, offsets, stride, n, nullptr, nullptr, nullptr};
+  LaunchCfg cfg{dfa->numCUs, 0};
+  hipError_t e = launchWalked(dfa->im->dev, b, do_leader ? 1 : 0,
+                              reinterpret_cast<unsigned long long *>(walked), cfg,
+                              static_cast<hipStream_t>(stream));
+  tlsKernel = "k_walked";
+  if (e != hipSuccess) return failHip(e, "kernel launch");
+  return REDGPU_OK;
+}
+
+void redgpu_thread_release(void) { hostStageReleaseThread(); }
+
+uint64_t redgpu_scratch_entries(void) { return scratchEntries(); }
 
 int redgpu_dfa_tune_dev(redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,
                         uint64_t stride, uint64_t n, void *stream) {
@@ -771,36 +824,24 @@ int redgpu_dfa_tune(redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offset
   if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
   if (dfa->im->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
   if (n == 0) return REDGPU_OK;
+  if (offsets)
+    if (int rc = checkOffsets(offsets, n)) return rc;
   const uint64_t total = offsets ? offsets[n] : stride * n;
-  if (offsets) {
-    for (uint64_t i = 0; i < n; ++i)
-      if (offsets[i] > offsets[i + 1]) return fail(REDGPU_EAPI, "offsets not monotonic");
-  }
   if (total && !data) return fail(REDGPU_EAPI, "null data buffer");
   DeviceScope scope(dfa->im->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  HostStage *st = nullptr;
+  if (int rc = stageOf(dfa, &st)) return rc;
+  hipStream_t s = st->streams[0];
   uint8_t *dData = nullptr;
   uint64_t *dOff = nullptr;
-  auto cleanup = [&]() {
-    if (dData) (void)hipFree(dData);
-    if (dOff) (void)hipFree(dOff);
-  };
-  int rc = REDGPU_OK;
-#define TU_TRY(expr, what)                                                    \
-  do {                                                                        \
-    hipError_t e_ = (expr);                                                   \
-    if (e_ != hipSuccess) { rc = failHip(e_, what); cleanup(); return rc; }   \
-  } while (0)
-  TU_TRY(hipMalloc(reinterpret_cast<void **>(&dData), total + 16), "hipMalloc data");
+  STAGE_TRY(st->get(kSlData, total, reinterpret_cast<void **>(&dData)), "hipMalloc data");
   if (offsets) {
-    TU_TRY(hipMalloc(reinterpret_cast<void **>(&dOff), (n + 1) * 8), "hipMalloc offsets");
-    TU_TRY(hipMemcpy(dOff, offsets, (n + 1) * 8, hipMemcpyHostToDevice), "copy offsets");
+    STAGE_TRY(st->get(kSlOff, (n + 1) * 8, reinterpret_cast<void **>(&dOff)), "hipMalloc offsets");
+    STAGE_TRY(hipMemcpyAsync(dOff, offsets, (n + 1) * 8, hipMemcpyHostToDevice, s), "copy offsets");
   }
-  if (total) TU_TRY(hipMemcpy(dData, data, total, hipMemcpyHostToDevice), "copy data");
-#undef TU_TRY
-  rc = redgpu_dfa_tune_dev(dfa, dData, dOff, stride, n, nullptr);
-  cleanup();
-  return rc;
+  if (total) STAGE_TRY(hipMemcpyAsync(dData, data, total, hipMemcpyHostToDevice, s), "copy data");
+  return redgpu_dfa_tune_dev(dfa, dData, dOff, stride, n, s);  // synchronises
 }
 
 int redgpu_advance_batch_dev(const redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,
@@ -830,44 +871,36 @@ int redgpu_advance_batch(const redgpu_dfa *dfa, const uint8_t *data, const uint6
   if (n == 0) return REDGPU_OK;
   if (!state) return fail(REDGPU_EAPI, "null state buffer");
   if (!result) return fail(REDGPU_EAPI, "null result buffer");
+  if (offsets)
+    if (int rc = checkOffsets(offsets, n)) return rc;
   const uint64_t total = offsets ? offsets[n] : stride * n;
-  if (offsets) {
-    for (uint64_t i = 0; i < n; ++i)
-      if (offsets[i] > offsets[i + 1]) return fail(REDGPU_EAPI, "offsets not monotonic");
-  }
   if (total && !data) return fail(REDGPU_EAPI, "null data buffer");
   DeviceScope scope(dfa->im->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  HostStage *st = nullptr;
+  if (int rc = stageOf(dfa, &st)) return rc;
+  hipStream_t s = st->streams[0];
   uint8_t *dData = nullptr;
   uint64_t *dOff = nullptr;
   uint32_t *dState = nullptr;
   int32_t *dRes = nullptr;
-  auto cleanup = [&]() {
-    for (void *q : {(void *)dData, (void *)dOff, (void *)dState, (void *)dRes})
-      if (q) (void)hipFree(q);
-  };
-  int rc = REDGPU_OK;
-#define AD_TRY(expr, what)                                                    \
-  do {                                                                        \
-    hipError_t e_ = (expr);                                                   \
-    if (e_ != hipSuccess) { rc = failHip(e_, what); cleanup(); return rc; }   \
-  } while (0)
-  AD_TRY(hipMalloc(reinterpret_cast<void **>(&dData), total + 16), "hipMalloc data");
-  AD_TRY(hipMalloc(reinterpret_cast<void **>(&dState), n * 4), "hipMalloc state");
-  AD_TRY(hipMalloc(reinterpret_cast<void **>(&dRes), n * 4), "hipMalloc result");
+  STAGE_TRY(st->get(kSlData, total, reinterpret_cast<void **>(&dData)), "hipMalloc data");
+  STAGE_TRY(st->get(kSlAux0, n * 4, reinterpret_cast<void **>(&dState)), "hipMalloc state");
+  STAGE_TRY(st->get(kSlRes, n * 4, reinterpret_cast<void **>(&dRes)), "hipMalloc result");
   if (offsets) {
-    AD_TRY(hipMalloc(reinterpret_cast<void **>(&dOff), (n + 1) * 8), "hipMalloc offsets");
-    AD_TRY(hipMemcpy(dOff, offsets, (n + 1) * 8, hipMemcpyHostToDevice), "copy offsets");
+    STAGE_TRY(st->get(kSlOff, (n + 1) * 8, reinterpret_cast<void **>(&dOff)), "hipMalloc offsets");
+    STAGE_TRY(hipMemcpyAsync(dOff, offsets, (n + 1) * 8, hipMemcpyHostToDevice, s), "copy offsets");
   }
-  if (total) AD_TRY(hipMemcpy(dData, data, total, hipMemcpyHostToDevice), "copy data");
-  AD_TRY(hipMemcpy(dState, state, n * 4, hipMemcpyHostToDevice), "copy state");
-  rc = redgpu_advance_batch_dev(dfa, dData, dOff, stride, n, dState, dRes, nullptr);
-  if (rc != REDGPU_OK) { cleanup(); return rc; }
-  AD_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
-  AD_TRY(hipMemcpy(state, dState, n * 4, hipMemcpyDeviceToHost), "copy state back");
-  AD_TRY(hipMemcpy(result, dRes, n * 4, hipMemcpyDeviceToHost), "copy result");
-#undef AD_TRY
-  cleanup();
+  if (total) STAGE_TRY(hipMemcpyAsync(dData, data, total, hipMemcpyHostToDevice, s), "copy data");
+  STAGE_TRY(hipMemcpyAsync(dState, state, n * 4, hipMemcpyHostToDevice, s), "copy state");
+  const int rc = redgpu_advance_batch_dev(dfa, dData, dOff, stride, n, dState, dRes, s);
+  if (rc != REDGPU_OK) {
+    (void)st->sync();
+    return rc;
+  }
+  STAGE_TRY(hipMemcpyAsync(state, dState, n * 4, hipMemcpyDeviceToHost, s), "copy state back");
+  STAGE_TRY(hipMemcpyAsync(result, dRes, n * 4, hipMemcpyDeviceToHost, s), "copy result");
+  STAGE_TRY(hipStreamSynchronize(s), "hipStreamSynchronize");
   return REDGPU_OK;
 }
 

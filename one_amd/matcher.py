@@ -85,18 +85,27 @@ class Executable:
         o.device = (_lib.DEVICE_NONE if device == "none" else
                     _lib.DEVICE_CURRENT if device is None else int(device))
         o.lds_table_max = lds_table_max
-        o.flags = (_lib.F_FORCE_GENERIC if force_generic else 0) | \
-                  (_lib.F_FORCE_GLOBAL if force_global else 0) | \
-                  (_lib.F_FORCE_HOT if force_hot else 0) | \
-                  (_lib.F_NO_BUCKETING if no_bucketing else 0) | \
-                  (_lib.F_FORCE_STREAM if force_stream else 0) | \
-                  (_lib.F_NO_CHUNKING if no_chunking else 0) | \
-                  (_lib.F_FORCE_CHUNKING if force_chunking else 0) | \
-                  (_lib.F_STREAM_CHAINS_2 if stream_chains == 2 else 0) | \
-                  (_lib.F_STREAM_CHAINS_4 if stream_chains == 4 else 0)
+        o.flags = Executable._flags_of(force_generic=force_generic, force_global=force_global,
+                                       force_hot=force_hot, no_bucketing=no_bucketing,
+                                       force_stream=force_stream, no_chunking=no_chunking,
+                                       force_chunking=force_chunking, stream_chains=stream_chains)
         self._h = C.c_void_p()
         blob = bytes(serialized)
         _check(_lib.lib().redgpu_dfa_create(blob, len(blob), C.byref(o), C.byref(self._h)))
+
+    @staticmethod
+    def _flags_of(force_generic=False, force_global=False, force_hot=False, no_bucketing=False,
+                  force_stream=False, no_chunking=False, force_chunking=False, stream_chains=0,
+                  **_ignored) -> int:
+        return ((_lib.F_FORCE_GENERIC if force_generic else 0) |
+                (_lib.F_FORCE_GLOBAL if force_global else 0) |
+                (_lib.F_FORCE_HOT if force_hot else 0) |
+                (_lib.F_NO_BUCKETING if no_bucketing else 0) |
+                (_lib.F_FORCE_STREAM if force_stream else 0) |
+                (_lib.F_NO_CHUNKING if no_chunking else 0) |
+                (_lib.F_FORCE_CHUNKING if force_chunking else 0) |
+                (_lib.F_STREAM_CHAINS_2 if stream_chains == 2 else 0) |
+                (_lib.F_STREAM_CHAINS_4 if stream_chains == 4 else 0))
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None
@@ -228,6 +237,97 @@ def _run(verb: str, exe: Executable, style, do_leader, data, offsets, stride, n,
         rc = f(exe._h, style, lead, dp, op, stride, n, res.ctypes.data)
     _check(rc)
     return res, st, en
+
+
+_VERBS = {"check": _lib.VERB_CHECK, "match": _lib.VERB_MATCH, "scan": _lib.VERB_SCAN,
+          "search": _lib.VERB_SEARCH}
+
+
+class Group:
+    """One image of the same serialized DFA on each of several GPUs of a node (the device form
+    of tools/thr_red.cpp:84-91: N workers over one shared Red).  devices may repeat a device."""
+
+    def __init__(self, serialized: bytes, devices, **flags):
+        o = _lib.Opts()
+        o.flags = Executable._flags_of(**flags)
+        o.lds_table_max = flags.get("lds_table_max", 0)
+        devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        self._h = C.c_void_p()
+        blob = bytes(serialized)
+        _check(_lib.lib().redgpu_group_create(blob, len(blob), C.byref(o), devs, len(devices),
+                                              C.byref(self._h)))
+        self.devices = [int(d) for d in devices]
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None and getattr(_lib, "_lib", None) is not None:
+            _lib._lib.redgpu_group_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def plan(self, n, *, offsets=None, stride=0):
+        """cuts[0..G]: shard g = lines [cuts[g], cuts[g+1]) - equal lines, or equal bytes when
+        (host) offsets are given."""
+        cuts = np.zeros(len(self.devices) + 1, dtype=np.uint64)
+        op = None
+        if offsets is not None:
+            offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+            op = offsets.ctypes.data
+        _check(_lib.lib().redgpu_group_plan(self._h, op, stride, n, cuts.ctypes.data))
+        return cuts
+
+    def batch(self, verb, data, style, do_leader=True, *, offsets=None, stride=0, n=None):
+        """Host buffers: (result, start, end) over all shards, one host thread per device."""
+        a = _host_u8(data)
+        if offsets is not None:
+            offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+            n = len(offsets) - 1
+        elif n is None:
+            n = a.size // stride if stride else 0
+        pos = verb in ("match", "search")
+        res = np.zeros(n, dtype=np.int32)
+        st = np.zeros(n, dtype=np.uint64) if pos else None
+        en = np.zeros(n, dtype=np.uint64) if pos else None
+        _check(_lib.lib().redgpu_group_batch(
+            self._h, _VERBS[verb], int(style), 1 if do_leader else 0,
+            a.ctypes.data if a.size else None,
+            offsets.ctypes.data if offsets is not None else None, int(stride or 0), n,
+            res.ctypes.data, st.ctypes.data if pos else None, en.ctypes.data if pos else None))
+        return res, st, en
+
+    def batch_dev(self, verb, shards, style, do_leader=True, *, stride=0, gather="peer"):
+        """Device-resident shards: shards[g] = CUDA uint8 tensor on device g, or (data, offsets)
+        for ragged lines.  Returns (result, start, end) CUDA tensors on devices[0], complete on
+        torch's current stream of that device."""
+        import torch
+        G = len(self.devices)
+        assert len(shards) == G
+        datas, offs, ns = [], [], []
+        for sh in shards:
+            d, o = sh if isinstance(sh, tuple) else (sh, None)
+            datas.append(d)
+            offs.append(o)
+            ns.append((o.numel() - 1) if o is not None else (d.numel() // stride if stride else 0))
+        ragged = offs[0] is not None
+        total = sum(ns)
+        root = torch.device("cuda", self.devices[0])
+        pos = verb in ("match", "search")
+        res = torch.empty(total, dtype=torch.int32, device=root)
+        st = torch.empty(total, dtype=torch.int64, device=root) if pos else None
+        en = torch.empty(total, dtype=torch.int64, device=root) if pos else None
+        dp = (C.c_void_p * G)(*[d.data_ptr() for d in datas])
+        op = (C.c_void_p * G)(*[o.data_ptr() for o in offs]) if ragged else None
+        na = (C.c_uint64 * G)(*ns)
+        _check(_lib.lib().redgpu_group_batch_dev(
+            self._h, _VERBS[verb], int(style), 1 if do_leader else 0, dp, op, int(stride or 0), na,
+            res.data_ptr(), st.data_ptr() if pos else None, en.data_ptr() if pos else None,
+            _lib.GATHER_RCCL if gather == "rccl" else _lib.GATHER_PEER,
+            torch.cuda.current_stream(root).cuda_stream))
+        return res, st, en
 
 
 def check_batch(exe, data, style, do_leader=True, *, offsets=None, stride=0, n=None, out=None):

@@ -1,0 +1,208 @@
+"""GPU tests of the boundary itself (all through the C-ABI): the reference's threading contract
+(doc/Performance.md:81-84, tools/thr_red.cpp:84-91 - N host threads over one shared handle), the
+chunk-pipelined host-buffer path, per-thread staging, and the several-GPU group (shards, compact
+record gather) rehearsed on one device."""
+import threading
+
+import numpy as np
+import pytest
+
+import one_amd
+import oracle as O
+from golden_util import load_dfa
+from one_amd import _lib
+from one_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _eq(got, exp):
+    return all((g is None and e is None) or np.array_equal(np.asarray(g).astype(np.uint64),
+                                                           np.asarray(e).astype(np.uint64))
+               for g, e in zip(got, exp))
+
+
+def test_eight_host_threads_share_one_handle():
+    """8 host threads hammer ONE redgpu_dfa: host-buffer calls (fixed and ragged lines, two
+    handles' worth of table kinds) and device-pointer calls on distinct streams, every result
+    compared with the oracle.  Staging and scratch are per thread / per stream."""
+    import torch
+    blob = load_dfa("syn256")
+    exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
+    uri = load_dfa("uri")
+    exe2, cpu2 = one_amd.Executable(uri), O.CpuOracle(uri)
+    n, stride = 6000, 64
+    fixed = [W.fixed_lines(n, stride, 100 + t, alphabet=False) for t in range(8)]
+    ragged = [W.ragged_lines(3000 + 17 * t, 1, 300, 200 + t, heads=[W.URI_PLANT], head_every=3)
+              for t in range(8)]
+    exp_fixed = [cpu.batch("match", 4, 0, f, stride=stride, n=n, threads=4) for f in fixed]
+    exp_ragged = [cpu2.batch("match", 4, 0, d, offsets=o, threads=4) for d, o in ragged]
+    exp_scan = [cpu2.batch("scan", 1, 1, d, offsets=o, threads=4)[0] for d, o in ragged]
+    dev_in = [torch.from_numpy(f).cuda() for f in fixed]
+    errors = []
+
+    def worker(t):
+        try:
+            stream = torch.cuda.Stream()
+            for rep in range(6):
+                got = one_amd.match_batch(exe, fixed[t], 4, 0, stride=stride, n=n)
+                assert _eq(got, exp_fixed[t]), ("host fixed", t, rep)
+                d, o = ragged[t]
+                got = one_amd.match_batch(exe2, d, 4, 0, offsets=o)
+                assert _eq(got, exp_ragged[t]), ("host ragged", t, rep)
+                assert np.array_equal(one_amd.scan_batch(exe2, d, 1, 1, offsets=o), exp_scan[t])
+                with torch.cuda.stream(stream):
+                    r, s, e = one_amd.match_batch(exe, dev_in[t], 4, 0, stride=stride, n=n)
+                    stream.synchronize()
+                assert _eq((r.cpu().numpy(), s.cpu().numpy(), e.cpu().numpy()), exp_fixed[t]), \
+                    ("dev fixed", t, rep)
+            _lib.lib().redgpu_thread_release()
+        except BaseException as ex:  # noqa: BLE001 - reported by the main thread
+            errors.append(repr(ex))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    # scratch is pooled per (device, stream), bounded, and the threads' own streams took theirs along
+    assert _lib.lib().redgpu_scratch_entries() <= 64
+
+
+def test_short_lived_threads_do_not_accumulate_scratch():
+    """The shape of tools/thr_red.cpp: workers come and go.  Each one's staging (streams, device
+    buffers, the ragged launches' scratch on those streams) goes with it."""
+    blob = load_dfa("uri")
+    exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
+    d, o = W.ragged_lines(20000, 1, 200, 9, heads=[W.URI_PLANT], head_every=4)
+    exp = cpu.batch("match", 4, 0, d, offsets=o, threads=4)
+    base = _lib.lib().redgpu_scratch_entries()
+    errors = []
+
+    def worker():
+        try:
+            assert _eq(one_amd.match_batch(exe, d, 4, 0, offsets=o), exp)
+        except BaseException as ex:  # noqa: BLE001
+            errors.append(repr(ex))
+
+    for _ in range(12):
+        th = threading.Thread(target=worker)
+        th.start()
+        th.join()
+    assert not errors, errors
+    assert _lib.lib().redgpu_scratch_entries() <= base + 1
+
+
+@pytest.mark.parametrize("shape", ["fixed", "ragged"])
+def test_host_path_chunk_pipeline_vs_oracle(shape):
+    """Host buffers of several chunks (> 64 MiB): chunks alternate between the thread's two
+    streams, ragged chunks run against a shifted base with absolute offsets."""
+    blob = load_dfa("syn256")
+    exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
+    if shape == "fixed":
+        n, stride = (1 << 20) + 777, 128
+        data = W.fixed_lines(n, stride, 77, alphabet=False)
+        got = one_amd.match_batch(exe, data, 4, 0, stride=stride, n=n)
+        exp = cpu.batch("match", 4, 0, data, stride=stride, n=n, threads=8)
+        assert _eq(got, exp)
+        assert np.array_equal(one_amd.check_batch(exe, data, 5, 0, stride=stride, n=n),
+                              cpu.batch("check", 5, 0, data, stride=stride, n=n, threads=8)[0])
+    else:
+        data, offs = W.ragged_lines(1 << 20, 1, 300, 78, alphabet=False)
+        assert int(offs[-1]) > (3 * 32 << 20)
+        got = one_amd.match_batch(exe, data, 4, 0, offsets=offs)
+        exp = cpu.batch("match", 4, 0, data, offsets=offs, threads=8)
+        assert _eq(got, exp)
+        # a sub-batch whose first offset is not 0
+        sub = offs[1000:900000]
+        got = one_amd.match_batch(exe, data, 4, 0, offsets=sub)
+        exp = cpu.batch("match", 4, 0, data, offsets=sub, threads=8)
+        assert _eq(got, exp)
+
+
+def test_list_verbs_validate_their_arguments():
+    """collect / matchAll host entry points reject what the other verbs reject."""
+    blob = load_dfa("uri")
+    exe = one_amd.Executable(blob)
+    data = np.frombuffer(b"x" * 100, dtype=np.uint8)
+    bad = np.array([0, 50, 40, 100], dtype=np.uint64)
+    with pytest.raises(one_amd.RedExceptApi):
+        one_amd.collect_batch(exe, data, 4, offsets=bad)
+    with pytest.raises(one_amd.RedExceptApi):
+        one_amd.match_all_batch(exe, data, 4, offsets=bad)
+    # n * cap overflow is refused before anything is sized by it
+    offs = np.array([0, 50, 100], dtype=np.uint64)
+    small = np.zeros(16, dtype=np.uint64)
+    rc = _lib.lib().redgpu_collect_batch(exe._h, data.ctypes.data, offs.ctypes.data, 0, 2, 1 << 62,
+                                         small.ctypes.data, small.ctypes.data, small.ctypes.data,
+                                         small.ctypes.data)
+    assert rc == _lib.ELIMIT
+
+
+@pytest.mark.parametrize("ndev", [1, 3])
+def test_group_host_batches_vs_oracle(ndev):
+    """redgpu_group_batch: shards by lines (fixed) and by bytes (ragged), one host thread per
+    device - the same device named ndev times here - results in the caller's arrays."""
+    blob = load_dfa("uri")
+    cpu = O.CpuOracle(blob)
+    grp = one_amd.Group(blob, [0] * ndev)
+    n, stride = 50001, 64
+    data = W.fixed_lines(n, stride, 5, plant=W.URI_PLANT)
+    cuts = grp.plan(n, stride=stride)
+    assert cuts[0] == 0 and cuts[-1] == n and np.all(np.diff(cuts.astype(np.int64)) >= n // ndev)
+    for verb, style, lead in (("match", 4, 0), ("match", 5, 1), ("search", 4, 0)):
+        got = grp.batch(verb, data, style, lead, stride=stride, n=n)
+        exp = cpu.batch(verb, style, lead, data, stride=stride, n=n, threads=8)
+        assert _eq(got, exp), (verb, style, lead)
+    assert np.array_equal(grp.batch("check", data, 4, 0, stride=stride, n=n)[0],
+                          cpu.batch("check", 4, 0, data, stride=stride, n=n, threads=8)[0])
+    rd, ro = W.ragged_lines(40000, 1, 400, 6, heads=[W.URI_PLANT], head_every=3)
+    cuts = grp.plan(len(ro) - 1, offsets=ro)
+    per = [int(ro[int(cuts[g + 1])] - ro[int(cuts[g])]) for g in range(ndev)]
+    assert max(per) - min(per) <= 400 * 2  # balanced by BYTES to within a line or two
+    got = grp.batch("match", rd, 4, 0, offsets=ro)
+    assert _eq(got, cpu.batch("match", 4, 0, rd, offsets=ro, threads=8))
+    assert np.array_equal(grp.batch("scan", rd, 1, 0, offsets=ro)[0],
+                          cpu.batch("scan", 1, 0, rd, offsets=ro, threads=8)[0])
+
+
+@pytest.mark.parametrize("ndev,gather", [(1, "peer"), (3, "peer"), (1, "rccl")])
+def test_group_device_shards_gathered_on_root(ndev, gather):
+    """redgpu_group_batch_dev: device-resident shards scanned on per-device streams, compact
+    records (1-byte results, 1/2-byte positions here) moved to the root and widened there."""
+    import torch
+    for name, stride in (("syn256", 64), ("uri", 4096)):
+        blob = load_dfa(name)
+        cpu = O.CpuOracle(blob)
+        grp = one_amd.Group(blob, [0] * ndev)
+        counts = [3000 + 11 * g for g in range(ndev)]
+        hosts = [W.fixed_lines(c, stride, 40 + g, alphabet=(name != "syn256"),
+                               plant=(W.URI_PLANT if name == "uri" else None))
+                 for g, c in enumerate(counts)]
+        shards = [torch.from_numpy(h).cuda() for h in hosts]
+        for rep in range(3):  # the root record buffer is reused call after call
+            r, s, e = grp.batch_dev("match", shards, 4, 0, stride=stride, gather=gather)
+            torch.cuda.synchronize()
+            exp = [cpu.batch("match", 4, 0, h, stride=stride, n=c, threads=4)
+                   for h, c in zip(hosts, counts)]
+            cat = [np.concatenate([x[k] for x in exp]) for k in range(3)]
+            assert _eq((r.cpu().numpy(), s.cpu().numpy(), e.cpu().numpy()), cat), (name, rep)
+        rc = grp.batch_dev("check", shards, 5, 0, stride=stride, gather=gather)[0]
+        torch.cuda.synchronize()
+        expc = np.concatenate([cpu.batch("check", 5, 0, h, stride=stride, n=c, threads=4)[0]
+                               for h, c in zip(hosts, counts)])
+        assert np.array_equal(rc.cpu().numpy(), expc)
+    # ragged shards: offsets relative to each shard's data
+    blob = load_dfa("uri")
+    cpu = O.CpuOracle(blob)
+    grp = one_amd.Group(blob, [0] * ndev)
+    parts = [W.ragged_lines(5000 + g, 1, 700, 60 + g, heads=[W.URI_PLANT], head_every=3)
+             for g in range(ndev)]
+    shards = [(torch.from_numpy(d).cuda(), torch.from_numpy(o.astype(np.int64)).cuda())
+              for d, o in parts]
+    r, s, e = grp.batch_dev("match", shards, 4, 0, gather=gather)
+    torch.cuda.synchronize()
+    exp = [cpu.batch("match", 4, 0, d, offsets=o, threads=4) for d, o in parts]
+    cat = [np.concatenate([x[k] for x in exp]) for k in range(3)]
+    assert _eq((r.cpu().numpy(), s.cpu().numpy(), e.cpu().numpy()), cat)

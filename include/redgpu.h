@@ -18,6 +18,9 @@
  *     doc/Performance.md:81-84, tools/thr_red.cpp:86-91).
  *   - inputs: line i is data[offsets[i], offsets[i+1]) when offsets != NULL (n+1 entries),
  *     else data[i*stride, (i+1)*stride).  Inputs/outputs are caller-owned and never retained.
+ *     Device-pointer (_dev) entry points may read any byte of data[0, offsets[n]) (idle lanes
+ *     re-read the first block), so the whole range must be device memory even when
+ *     offsets[0] > 0; the host-buffer entry points copy only [offsets[0], offsets[n]).
  *   - outputs are the fields of the reference's Outcome (include/Outcome.h:32-35):
  *     result int32, start/end uint64 (size_t).  `start` and `end` may be NULL.
  *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails

@@ -286,7 +286,8 @@ int redgpu_group_batch(const redgpu_group *g, int verb, int style, int do_leader
     const uint64_t lo = cuts[k], nl = cuts[k + 1] - lo;
     if (!nl) return;
     const redgpu_dfa *d = g->m[k].dfa;
-    // ragged: absolute offsets stay valid against the unshifted data pointer
+    // ragged: the shard's slice of the offsets against the unshifted data pointer (the host
+    // entry point copies [offsets[lo], offsets[hi]) and rebases)
     const uint8_t *p = offsets ? data : data + lo * stride;
     const uint64_t *o = offsets ? offsets + lo : nullptr;
     int rc;

@@ -98,6 +98,16 @@ enum StageSlot : int {
 
 constexpr uint64_t kHostChunkBytes = 32ull << 20;
 
+// offsets of a chunk that does not start at byte 0, rebased to the chunk's own buffer: the
+// kernels may read data[0, offsets[n]) anywhere (lanes without a line re-read block 0), so a
+// chunk is always presented as a batch of its own
+__global__ void __launch_bounds__(256)
+k_rebase(const uint64_t *in, uint64_t n1, uint64_t base, uint64_t *out) {
+  const uint64_t step = uint64_t(gridDim.x) * 256;
+  for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n1; i += step)
+    out[i] = in[i] - base;
+}
+
 // host-buffer form: the batch is cut into chunks of ~32 MiB of input that alternate between the
 // thread's two private streams - copy in, kernel, copy out per chunk - so that with pinned
 // caller memory (registered for the duration of the call when the batch has several chunks)
@@ -166,8 +176,14 @@ int runHost(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint
     if (end)
       STAGE_TRY(st->get(kSlEnd + k, maxLines * 8, reinterpret_cast<void **>(&dEnd[k])), "hipMalloc end");
   }
-  if (offsets)
+  uint64_t *dReb[2] = {nullptr, nullptr};
+  if (offsets) {
     STAGE_TRY(st->get(kSlOff, (n + 1) * 8, reinterpret_cast<void **>(&dOff)), "hipMalloc offsets");
+    if (multi || base0)
+      for (int k = 0; k < (multi ? 2 : 1); ++k)
+        STAGE_TRY(st->get(kSlAux0 + k, (maxLines + 1) * 8, reinterpret_cast<void **>(&dReb[k])),
+                  "hipMalloc chunk offsets");
+  }
 
   // pinned caller memory makes the copies truly asynchronous (only worth its price when there
   // is something to overlap)
@@ -190,10 +206,15 @@ int runHost(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint
     const uint64_t bytes = offsets ? offsets[hi] - byteLo : nl * stride;
     if (bytes)
       STAGE_TRY(hipMemcpyAsync(dData[k], data + byteLo, bytes, hipMemcpyHostToDevice, s), "copy data");
-    // ragged: absolute offsets against a base shifted back by the chunk's first byte
-    const uint8_t *base = offsets ? dData[k] - byteLo : dData[k];
-    const int rc = runDev(dfa, verb, style, doLeader, base, offsets ? dOff + lo : nullptr, stride,
-                          nl, dRes[k], dStart[k], dEnd[k], s);
+    const uint64_t *chunkOff = offsets ? dOff + lo : nullptr;
+    if (offsets && byteLo) {
+      const uint32_t blocks = uint32_t((nl + 256) / 256 < 1024 ? (nl + 256) / 256 : 1024);
+      hipLaunchKernelGGL(k_rebase, dim3(blocks), dim3(256), 0, s, dOff + lo, nl + 1, byteLo,
+                         dReb[k]);
+      chunkOff = dReb[k];
+    }
+    const int rc = runDev(dfa, verb, style, doLeader, dData[k], chunkOff, stride, nl, dRes[k],
+                          dStart[k], dEnd[k], s);
     if (rc != REDGPU_OK) {
       (void)st->sync();
       return rc;

@@ -97,7 +97,7 @@ def test_short_lived_threads_do_not_accumulate_scratch():
 @pytest.mark.parametrize("shape", ["fixed", "ragged"])
 def test_host_path_chunk_pipeline_vs_oracle(shape):
     """Host buffers of several chunks (> 64 MiB): chunks alternate between the thread's two
-    streams, ragged chunks run against a shifted base with absolute offsets."""
+    streams; the offsets of a ragged chunk are rebased on the device to the chunk's own buffer."""
     blob = load_dfa("syn256")
     exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
     if shape == "fixed":

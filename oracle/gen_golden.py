@@ -8,7 +8,7 @@ them - plus the expected values the reference's own gtest files assert, transcri
 No reference source text is stored.
 
 Outputs (all under tests/golden/):
-  dfas/<name>.reda            blobs of the BASELINE config DFAs (reference compiler output)
+  dfas/<name>.reda[.xz]       blobs of the BASELINE config DFAs (reference compiler output)
   kat_matcher.json            known answers asserted by test/matcher.cpp, test/executable.cpp,
                               test/serializer.cpp, test/fnv.cpp (+ the blobs, per format)
   omnibus.json(+.npz)         the 160-row {regex,text,shouldMatch} table of
@@ -326,6 +326,9 @@ def config_dfas():
     d["uri"] = O.ref_compile([(W.URI_REGEX, 1, O.F_LOOSE_START)])
     d["log100"] = O.ref_compile(W.log100_patterns())
     d["syn256"] = O.ref_syn_dfa(256, 42)
+    # BASELINE configs[4]'s "~4 K-state DFA": dense random, through the reference's minimizer +
+    # serializer like SYN-256 (4,097 states x 256 classes, fmtDirect4, 4.2 MB: stored xz-compressed)
+    d["syn4k"] = O.ref_syn_dfa(4096, 5)
     d["num3"] = O.ref_compile(NUM3)
     d["newyork"] = O.ref_compile([("New", 1, LS), ("New York", 2, LS), ("York", 3, LS)])
     d["aab"] = O.ref_compile([("aab", 1, 0)])
@@ -369,8 +372,13 @@ def gen_vectors(only=None):
     for name, blob in dfas.items():
         if only and name not in only:
             continue
-        with open(os.path.join(GOLD, "dfas", name + ".reda"), "wb") as f:
-            f.write(blob)
+        if len(blob) > (1 << 20):
+            import lzma
+            with open(os.path.join(GOLD, "dfas", name + ".reda.xz"), "wb") as f:
+                f.write(lzma.compress(blob, preset=6))
+        else:
+            with open(os.path.join(GOLD, "dfas", name + ".reda"), "wb") as f:
+                f.write(blob)
         info = O.CpuOracle(blob).info
         print("dfa %-12s %8d B  %s" % (name, len(blob), info))
         rng = np.random.default_rng(0xC0FFEE)

@@ -8,7 +8,7 @@ import numpy as np
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 STYLES = ["instant", "first", "tangent", "last", "full"]
 CONFIG_DFAS = ["err", "uri", "log100", "syn256", "num3", "newyork", "aab", "dotstar_err",
-               "uri_v6", "uri_user"]
+               "uri_v6", "uri_user", "syn4k"]
 
 
 def unb64(s):
@@ -35,9 +35,21 @@ def load_omnibus():
     return meta["rows"], blobs
 
 
+_DFA_CACHE = {}
+
+
 def load_dfa(name):
-    with open(os.path.join(GOLD, "dfas", name + ".reda"), "rb") as f:
-        return f.read()
+    """The reference-compiled blob of a config DFA (big ones are stored xz-compressed)."""
+    if name not in _DFA_CACHE:
+        path = os.path.join(GOLD, "dfas", name + ".reda")
+        if os.path.exists(path):
+            with open(path, "rb") as f:
+                _DFA_CACHE[name] = f.read()
+        else:
+            import lzma
+            with open(path + ".xz", "rb") as f:
+                _DFA_CACHE[name] = lzma.decompress(f.read())
+    return _DFA_CACHE[name]
 
 
 def load_vectors(name):

@@ -1006,7 +1006,7 @@ def test_full_size_config5_long_inputs_sample():
     halves property."""
     import torch
     n, L = 1 << 16, 1 << 16
-    blob = random_dfa(4097, 256, 5, accept_frac=0.1)
+    blob = load_dfa("syn4k")  # SYN-4K as the reference's minimizer + serializer wrote it
     exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
     g = torch.Generator(device="cuda").manual_seed(5)
     data = torch.empty(n * L, dtype=torch.uint8, device="cuda")
@@ -1084,7 +1084,11 @@ def test_config4_shape_log100_ragged_vs_oracle():
 def test_config5_shape_4k_state_dfa_long_inputs_vs_oracle():
     """BASELINE configs[4] shape at reduced count: ~4K-state / 256-class DFA (2 MiB table,
     L2-resident gather), 64 KiB inputs."""
-    blob = random_dfa(4097, 256, 5, accept_frac=0.1)
+    for blob in (load_dfa("syn4k"), random_dfa(4097, 256, 5, accept_frac=0.1)):
+        _config5_shape(blob)
+
+
+def _config5_shape(blob):
     exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
     assert exe.info["table_kind"] in (4, 5)
     n, stride = 512, 65536

@@ -58,12 +58,12 @@ def test_random_regex_dfas(seed):
     _compare_lists(blob, data, offsets)
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(5))
 def test_writer_blobs_accepted_by_reference(seed):
     """reda_writer's synthetic blobs are valid REDA to the reference, and both matchers agree
-    on them (incl. reachable pure dead ends)."""
-    n_states = [5, 40, 300, 700][seed]
-    n_cls = [3, 17, 256, 64][seed]
+    on them (incl. reachable pure dead ends; up to the 4,097 states of configs[4]'s shape)."""
+    n_states = [5, 40, 300, 700, 4097][seed]
+    n_cls = [3, 17, 256, 64, 256][seed]
     blob = random_dfa(n_states, n_cls, seed, dead_frac=0.05 if seed % 2 else 0.0)
     assert O.ref_check_header(blob) is None
     rng = np.random.default_rng(seed + 100)

@@ -1,24 +1,31 @@
 #!/usr/bin/env python3
 """bench.py - GB/s of input scanned by the MI355X DFA match-execution path.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config {1,2,3,4}] [--dfa NAME]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" = one pass of the hot path (match<styLast,false> = "matchLong", full Outcome:
-result + start + end) over one batch of synthetic input already resident in HBM.
-Workload at every N = BASELINE.json configs[1], per GPU: the 256-state / 256-class DFA
-(tests/golden/dfas/syn256.reda, produced by the reference's minimizer + serializer) over
-2^20 lines x 64 B = 64 MiB of uniform random bytes; >= 5 distinct input buffers are rotated so
-that no step finds its input in the 256 MiB Infinity Cache.  N > 1: one process per GPU,
-weak scaling (every rank scans its own shard, no data-path collective); the final step's
-per-line Outcomes are gathered to rank 0 over RCCL (compact wire records, widened on rank 0)
-once, at the end, INSIDE the timed region - "RCCL over xGMI only for the final result gather".
-(A gather after every step cannot scale for 64-byte lines: 3 bytes of results per 64 bytes of
-input is 1/21 of the scan rate per GPU, well above what an xGMI link carries - DESIGN.md.)
+A "step" = one pass of the hot path over one batch of synthetic input already resident in HBM.
+Workloads are BASELINE.json's configs, all through the C-ABI (include/redgpu.h):
 
-Prints ONE JSON line on rank 0 (see the driver's contract) with `roofline` (dominant kernel
-vs the 8 TB/s HBM peak, timed with events on the launch stream) and `cpu_baseline` (the
-reference's CPU matcher on this box's host cores, rank 0, N = 1 only).
+  --config 1 (default at N = 1)  SYN-256 (256 states / 256 classes) or --dfa uri (URI-D on text),
+             2^20 lines x 64 B per GPU, match<styLast,false> -> result + start + end.
+  --config 2 (default at N > 1)  the same DFAs, 2^21 lines x 4 KiB = 8 GiB per GPU (one GPU's
+             shard of the 16 M-line batch), full Outcome; N > 1: EVERY step's Outcomes are
+             gathered to rank 0 over RCCL (compact records, pipelined against the next scans).
+  --config 3 LOG-100 (100 signatures -> one DFA), 2^23 ragged lines of 32..256 B,
+             matchLong = match<styLast,true>; the bytes the walk actually reads are reported
+             beside the bytes of the lines (half of the lines die in their first bytes).
+  --config 4 SYN-4K (4,096 states / 256 classes, 2 MiB table in L2) or --dfa uri_v6,
+             65,536 inputs x 64 KiB = 4 GiB.
+
+Prints ONE JSON line on rank 0: the driver's contract plus `roofline` (dominant kernel: algorithmic
+bytes per launch / its average launch duration, HIP events on the launch stream, against the
+8 TB/s HBM peak; every other number in it is measured by THIS run - the read ceiling and the
+LDS gather roof by calibration kernels - except `traffic`, which is null unless a PMC summary
+of the same command is on disk, and then says where it comes from) and `cpu_baseline` (the
+reference's own CPU matcher on this box's host cores, rank 0, N = 1 only).  After the timed
+region the last output of every stream is checked against the CPU oracle (bit-exact or the
+run is invalid).
 """
 from __future__ import annotations
 
@@ -31,80 +38,236 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+L2_PEAK_GLOOKUPS = 269.5  # same guide: L2 ~34.5 TB/s aggregate = 269.5 G 128-byte requests / s
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--lines", type=int, default=1 << 20)
-    ap.add_argument("--line-len", type=int, default=64)
-    ap.add_argument("--dfa", default="syn256", choices=["syn256", "uri"])
-    ap.add_argument("--buffers", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=None, choices=[1, 2, 3, 4],
+                    help="BASELINE.json configs[k]; default 1 at N = 1, 2 at N > 1")
+    ap.add_argument("--dfa", default=None,
+                    help="syn256 | uri (configs 1, 2), log100 (3), syn4k | uri_v6 (4)")
+    ap.add_argument("--lines", type=int, default=None, help="override the config's line count")
+    ap.add_argument("--buffers", type=int, default=None)
     ap.add_argument("--no-start", action="store_true", help="outputs result + end only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-calibration", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=None,
                     help="HIP streams the steps are issued on round-robin (independent batches "
-                         "overlap: one step's ramp-up hides under the previous step's tail)")
+                         "overlap: one step's ramp-up hides under the previous step's tail); "
+                         "default 3 for config 1, else 1")
     return ap.parse_args()
 
 
-def make_inputs(args, rank, torch, W):
-    """Distinct per-rank, per-buffer synthetic batches, generated on the host with the same
-    counter-based generator the tests use, then made resident in HBM."""
-    import numpy as np
-    bufs, hosts = [], []
-    for k in range(args.buffers):
-        seed = 42 + 1000 * rank + k
-        if args.dfa == "syn256":
-            h = W.fixed_lines(args.lines, args.line_len, seed, alphabet=False)
+# ------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------
+class Workload:
+    """One config: device-resident rotating inputs, C-ABI call tuples, checker, CPU sample."""
+
+    def __init__(self, args, rank, torch, W, one_amd, oracle):
+        self.args, self.rank, self.torch, self.W, self.one_amd, self.oracle = \
+            args, rank, torch, W, one_amd, oracle
+        c = args.config
+        defaults = {1: "syn256", 2: "syn256", 3: "log100", 4: "syn4k"}
+        self.dfa_name = args.dfa or defaults[c]
+        from tests.golden_util import load_dfa
+        self.blob = load_dfa(self.dfa_name)
+        self.exe = one_amd.Executable(self.blob, device=torch.cuda.current_device())
+        self.info = self.exe.info
+        self.want_start = not args.no_start
+        self.style, self.lead = int(one_amd.styLast), 0
+        self.offsets_dev = None
+        self.ragged = False
+        self.text = self.dfa_name not in ("syn256", "syn4k")
+        if c == 1:
+            self.n, self.L = args.lines or (1 << 20), 64
+            self.nbuf = args.buffers or 6
+            self.label = "configs[1]"
+        elif c == 2:
+            self.n, self.L = args.lines or (1 << 21), 4096
+            self.nbuf = args.buffers or 2
+            self.label = "configs[2] (one GPU's shard of 16 M lines x 4 KiB)"
+        elif c == 3:
+            self.n, self.L = args.lines or (1 << 23), 0
+            self.nbuf = 1
+            self.lead = 1
+            self.ragged = True
+            self.label = "configs[3]"
         else:
-            h = W.fixed_lines(args.lines, args.line_len, seed, plant=W.URI_PLANT)
-        t = torch.from_numpy(h).cuda()
-        bufs.append(t)
-        hosts.append(h if k == 0 else None)
-    return bufs, hosts[0]
+            self.n, self.L = args.lines or (1 << 16), 1 << 16
+            self.nbuf = args.buffers or 2
+            self.label = "configs[4]"
+        self._build_inputs()
+
+    # -- inputs ----------------------------------------------------------------------------
+    def _build_inputs(self):
+        torch, W, a = self.torch, self.W, self.args
+        c, n, L = a.config, self.n, self.L
+        self.bufs, self.hosts = [], []
+        if c == 1:
+            for k in range(self.nbuf):
+                seed = 42 + 1000 * self.rank + k
+                h = (W.fixed_lines(n, L, seed, plant=W.URI_PLANT) if self.text else
+                     W.fixed_lines(n, L, seed, alphabet=False))
+                self.bufs.append(torch.from_numpy(h).cuda())
+                self.hosts.append(h)
+            self.in_bytes = n * L
+        elif c in (2, 4):
+            # generated on the device (8 / 4 GiB per buffer); the checker pulls samples back
+            alpha = torch.from_numpy(W.ALPHABET47.copy()).cuda()
+            plant = torch.from_numpy(__import__("numpy").frombuffer(W.URI_PLANT, dtype="uint8").copy()).cuda()
+            for k in range(self.nbuf):
+                g = torch.Generator(device="cuda").manual_seed(3 + 1000 * self.rank + k)
+                buf = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+                piece = 1 << 28
+                for lo in range(0, n * L, piece):
+                    hi = min(n * L, lo + piece)
+                    v = torch.randint(0, 256, (hi - lo,), generator=g, device="cuda",
+                                      dtype=torch.uint8)
+                    buf[lo:hi] = alpha[(v % 47).long()] if self.text else v
+                    del v
+                if self.text:  # a URL in every 8th line, as configs[1]'s text
+                    rows = buf.view(n, L)[::8]
+                    at = 1000 if L > 2000 else 8
+                    rows[:, at:at + plant.numel()] = plant
+                self.bufs.append(buf)
+            self.in_bytes = n * L
+        else:
+            data, offsets = W.ragged_lines(n, 32, 256, 4 + self.rank, heads=W.log100_heads(),
+                                           head_every=2)
+            self.hosts.append((data, offsets))
+            self.bufs.append(torch.from_numpy(data).cuda())
+            self.offsets_dev = torch.from_numpy(offsets.astype("int64")).cuda()
+            self.in_bytes = int(offsets[-1])
+        nout = max(3, 2 * (a.streams or 1))
+        self.outs = [(torch.empty(n, dtype=torch.int32, device="cuda"),
+                      torch.empty(n, dtype=torch.int64, device="cuda") if self.want_start else None,
+                      torch.empty(n, dtype=torch.int64, device="cuda")) for _ in range(nout)]
+        self.out_bytes = n * (4 + 8 + (8 if self.want_start else 0)) + (8 * n if self.ragged else 0)
+
+    # -- one step --------------------------------------------------------------------------
+    def call_tuple(self, i, stream):
+        r, s, e = self.outs[i % len(self.outs)]
+        buf = self.bufs[i % len(self.bufs)]
+        return (self.exe._h, self.style, self.lead, buf.data_ptr(),
+                self.offsets_dev.data_ptr() if self.ragged else None,
+                0 if self.ragged else self.L, self.n, r.data_ptr(),
+                s.data_ptr() if s is not None else None, e.data_ptr(), stream)
+
+    # -- checker: device outputs of (buffer b, output set o) against the CPU oracle ----------
+    def verify(self, b, o):
+        import numpy as np
+        torch = self.torch
+        cpu = self.oracle.CpuOracle(self.blob)
+        r, s, e = self.outs[o]
+        try:
+            threads = max(1, min(len(os.sched_getaffinity(0)), 32))
+        except AttributeError:
+            threads = 8
+
+        def same(idx, er, es, ee):
+            rr = r if idx is None else r[idx]
+            ok = np.array_equal(rr.cpu().numpy(), er)
+            ok = ok and np.array_equal((e if idx is None else e[idx]).cpu().numpy().astype(np.uint64), ee)
+            if self.want_start:
+                ok = ok and np.array_equal((s if idx is None else s[idx]).cpu().numpy().astype(np.uint64), es)
+            return bool(ok)
+
+        c = self.args.config
+        if c == 1:
+            er, es, ee = cpu.batch("match", "last", self.lead, self.hosts[b], stride=self.L,
+                                   n=self.n, threads=threads)
+            return same(None, er, es, ee), int((er > 0).sum())
+        if c == 3:
+            data, offsets = self.hosts[0]
+            ok, hits = True, 0
+            m = min(1 << 16, self.n)
+            for lo in (0, self.n - m):
+                so = offsets[lo:lo + m + 1]
+                sub = data[int(so[0]):int(so[-1])]
+                er, es, ee = cpu.batch("match", "last", self.lead, sub, offsets=so - so[0],
+                                       threads=threads)
+                idx = torch.arange(lo, lo + m, device="cuda")
+                ok = ok and same(idx, er, es, ee)
+                hits += int((er > 0).sum())
+            return ok, hits
+        # 2, 4: lines spread over the batch
+        m = min(self.n, 1 << (10 if c == 2 else 6))
+        idx = torch.arange(0, self.n, self.n // m, device="cuda")[:m]
+        sample = self.bufs[b].view(self.n, self.L)[idx].contiguous().cpu().numpy().reshape(-1)
+        er, es, ee = cpu.batch("match", "last", self.lead, sample, stride=self.L, n=len(idx),
+                               threads=threads)
+        return same(idx, er, es, ee), int((er > 0).sum())
+
+    def verify_note(self):
+        return {1: "every line of the last output of every stream vs the CPU oracle",
+                2: "1024 lines spread over the last output of every stream vs the CPU oracle",
+                3: "first and last 65,536 lines of the last output vs the CPU oracle",
+                4: "64 inputs spread over the last output of every stream vs the CPU oracle"}[
+                    self.args.config]
+
+    # -- the reference's CPU matcher on a bounded sample of the same workload -------------------
+    def cpu_sample(self):
+        import numpy as np
+        c = self.args.config
+        if c == 1:
+            return dict(data=self.hosts[0], stride=self.L, n=self.n), \
+                "the full %d x %d B batch" % (self.n, self.L)
+        if c == 3:
+            data, offsets = self.hosts[0]
+            m = min(self.n, 1 << 21)
+            so = offsets[:m + 1]
+            return dict(data=data[:int(so[-1])], offsets=so), \
+                "the first %d lines (%d bytes) of the batch" % (m, int(so[-1]))
+        m = min(self.n, (1 << 15) if c == 2 else (1 << 10))
+        idx = self.torch.arange(0, self.n, self.n // m, device="cuda")[:m]
+        sample = self.bufs[0].view(self.n, self.L)[idx].contiguous().cpu().numpy().reshape(-1)
+        return dict(data=sample, stride=self.L, n=m), \
+            "%d lines x %d B spread over buffer 0" % (m, self.L)
 
 
-def cpu_baseline(args, blob, host_batch):
-    """The reference's own CPU matcher (oracle/_ref, compiled from the reference sources) if
-    its prebuilt .so travelled with the repo, else the C restatement; all host cores, one
-    contiguous shard per thread as tools/thr_red.cpp:86-91 does.  Bounded to ~cpu_seconds."""
-    import oracle
+def cpu_baseline(args, wl, oracle):
+    """The reference's own CPU matcher (oracle/_ref, compiled from the reference sources) if its
+    prebuilt .so travelled with the repo, else the C restatement; all host cores of this box's
+    share, one contiguous shard per thread as tools/thr_red.cpp:86-91 does.  ~cpu_seconds."""
     try:
-        cores = len(os.sched_getaffinity(0))  # the box's CPU share, not the machine's
+        cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 64))
     if oracle.have_ref():
-        eng, kind = oracle.Reference(blob), "reference"
+        eng, kind = oracle.Reference(wl.blob), "reference"
     else:
-        eng, kind = oracle.CpuOracle(blob), "port"
-    n, L = args.lines, args.line_len
-    eng.batch("match", "last", 0, host_batch[: 4096 * L], stride=L, n=4096, threads=cores)
+        eng, kind = oracle.CpuOracle(wl.blob), "port"
+    kw, what = wl.cpu_sample()
+    data = kw.pop("data")
+    nbytes = int(kw["offsets"][-1]) if "offsets" in kw else kw["stride"] * kw["n"]
+    eng.batch("match", "last", wl.lead, data, threads=cores, **kw)  # warm
     t0 = time.perf_counter()
     passes = 0
     while True:
-        eng.batch("match", "last", 0, host_batch, stride=L, n=n, threads=cores)
+        eng.batch("match", "last", wl.lead, data, threads=cores, **kw)
         passes += 1
         dt = time.perf_counter() - t0
         if dt >= args.cpu_seconds or passes >= 200:
             break
-    gbs = passes * n * L / dt / 1e9
-    # single-thread figure for context
+    gbs = passes * nbytes / dt / 1e9
     t1 = time.perf_counter()
-    m = min(n, 1 << 18)
-    eng.batch("match", "last", 0, host_batch[: m * L], stride=L, n=m, threads=1)
-    one = m * L / (time.perf_counter() - t1) / 1e9
+    eng.batch("match", "last", wl.lead, data, threads=1, **kw)
+    one = nbytes / (time.perf_counter() - t1) / 1e9
     return {"value": round(gbs, 3), "unit": "GB/s", "cores": cores, "kind": kind,
-            "sample": "%d passes over the full %d x %d B batch, match<styLast,false>, "
-                      "%d threads" % (passes, n, L, cores),
+            "sample": "%d passes over %s, match<styLast,%s>, %d threads" %
+                      (passes, what, "true" if wl.lead else "false", cores),
             "single_thread_GBps": round(one, 3)}
 
 
+# ------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -122,6 +285,7 @@ def main():
     import numpy as np
     import torch
     import one_amd
+    from one_amd import _lib
     from one_amd import workloads as W
 
     rank = int(os.environ.get("RANK", "0"))
@@ -143,75 +307,60 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    with open(os.path.join(ROOT, "tests", "golden", "dfas", args.dfa + ".reda"), "rb") as f:
-        blob = f.read()
-    exe = one_amd.Executable(blob, device=local_rank)
-    info = exe.info
-    n, L = args.lines, args.line_len
-    want_start = not args.no_start
+    if args.config is None:
+        args.config = 1 if world == 1 else 2
+    if args.streams is None:
+        args.streams = 3 if (args.config == 1 and world == 1) else 1
+    if args.steps is None:
+        args.steps = {1: 300, 2: 20, 3: 40, 4: 5}[args.config]
+    if args.warmup is None:
+        args.warmup = {1: 30, 2: 3, 3: 5, 4: 1}[args.config]
 
-    bufs, host0 = make_inputs(args, rank, torch, W)
-    nout = 3
-    outs = [(torch.empty(n, dtype=torch.int32, device="cuda"),
-             torch.empty(n, dtype=torch.int64, device="cuda") if want_start else None,
-             torch.empty(n, dtype=torch.int64, device="cuda")) for _ in range(nout)]
+    import oracle  # checker and CPU baseline only - never inside a timed region
+    wl = Workload(args, rank, torch, W, one_amd, oracle)
+    info, n = wl.info, wl.n
 
-    streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else None
-    nout = max(nout, 2 * args.streams)
-    while len(outs) < nout:
-        outs.append((torch.empty(n, dtype=torch.int32, device="cuda"),
-                     torch.empty(n, dtype=torch.int64, device="cuda") if want_start else None,
-                     torch.empty(n, dtype=torch.int64, device="cuda")))
-
-    # The timed loop calls the C-ABI entry point directly (redgpu_match_batch_dev) with argument
-    # tuples built once: at ~20 us per kernel the Python conveniences of one_amd.match_batch
-    # (tensor checks, allocation) would make the loop host-bound.
-    from one_amd import _lib
     fn = _lib.lib().redgpu_match_batch_dev
     cur_stream = torch.cuda.current_stream().cuda_stream
-    period = len(bufs) * nout * max(1, args.streams)
-    calls = []
-    for i in range(period):
-        r_, s_, e_ = outs[i % nout]
-        st = streams[i % len(streams)].cuda_stream if streams else cur_stream
-        calls.append((exe._h, int(one_amd.styLast), 0, bufs[i % len(bufs)].data_ptr(), None, L, n,
-                      r_.data_ptr(), s_.data_ptr() if s_ is not None else None, e_.data_ptr(),
-                      st))
+    streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else None
+    period = len(wl.bufs) * len(wl.outs) * max(1, args.streams)
+    calls = [wl.call_tuple(i, streams[i % len(streams)].cuda_stream if streams else cur_stream)
+             for i in range(period)]
+    last_on_stream = {}
 
     def step(i):
         rc = fn(*calls[i % period])
         if rc != 0:
             raise RuntimeError(_lib.lib().redgpu_last_error().decode())
-        return outs[i % nout]
+        last_on_stream[i % max(1, args.streams)] = (i % len(wl.bufs), i % len(wl.outs))
+        return wl.outs[i % len(wl.outs)]
 
-    # ---- correctness gate: buffer 0 bit-exact against the CPU oracle ------------------------
-    import oracle
-    r, s, e = one_amd.match_batch(exe, bufs[0], one_amd.styLast, False, stride=L, n=n,
-                                  want_start=want_start, out=outs[0])
-    torch.cuda.synchronize()
-    try:
-        vthreads = max(1, min(len(os.sched_getaffinity(0)) // max(1, world), 32))
-    except AttributeError:
-        vthreads = 8
-    er, es, ee = oracle.CpuOracle(blob).batch("match", "last", 0, host0, stride=L, n=n,
-                                              threads=vthreads)
-    bit_exact = bool(np.array_equal(r.cpu().numpy(), er) and
-                     np.array_equal(e.cpu().numpy().astype(np.uint64), ee) and
-                     (not want_start or np.array_equal(s.cpu().numpy().astype(np.uint64), es)))
-    kernel_name = one_amd.last_kernel()
-
-    # ---- multi-GPU result gather (compact wire form, widened on rank 0) ---------------------
+    # ---- multi-GPU: every step's Outcomes gathered to rank 0 (compact records, pipelined) -------
     gather = None
     if world > 1:
         from one_amd import sharding
-        gather = sharding.FinalGather(info["max_result"], L, want_start,
-                                      via_host=(backend != "nccl"), equal_counts=True)
-
-    if gather:
-        # communicator set-up (RCCL connects lazily on the first collective) is not a step:
-        # one untimed gather of the correctness-gate outputs, whatever --warmup is
-        gather.push(outs[0])
+        max_len = wl.L if not wl.ragged else 256
+        gather = sharding.StepGather(n, info["max_result"], max_len, wl.want_start, depth=2,
+                                     via_host=(backend != "nccl"),
+                                     device="cuda" if backend == "nccl" else "cpu")
+        # RCCL connects lazily on the first collective: one untimed gather, whatever --warmup is
+        gather.push(step(0))
         gather.flush()
+
+    # rank 0 alone, untimed: the same per-GPU workload on ONE GPU, so that the weak-scaling
+    # reference of a multi-GPU line is this workload and not another config
+    solo = None
+    if world > 1:
+        if rank == 0:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            k = max(3, min(args.steps, 10))
+            for i in range(k):
+                step(i)
+            torch.cuda.synchronize()
+            solo = k * wl.in_bytes / (time.perf_counter() - t0) / 1e9
+        dist.barrier()
+
     for i in range(args.warmup):
         o = step(i)
         if gather:
@@ -219,7 +368,7 @@ def main():
     if streams is not None:
         for st in streams:
             torch.cuda.current_stream().wait_stream(st)
-    if gather and args.warmup:
+    if gather:
         gather.flush()
     torch.cuda.synchronize()
     if dist:
@@ -238,13 +387,14 @@ def main():
             torch.cuda.current_stream().wait_stream(st)
     ev1.record()
     if gather:
-        gather.flush()  # the final result gather: inside the timed region
+        gather.flush()  # the gathers still in flight: inside the timed region
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     region_ms = ev0.elapsed_time(ev1)
+    kernel_name = one_amd.last_kernel()
 
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64,
@@ -252,64 +402,139 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- dominant kernel's average launch duration, HIP events on its launch stream -----------
+    # ---- bit-exact gate: the last output each stream produced inside the timed loop -----------
+    bit_exact, matches = True, 0
+    checked = []
+    for sidx, (b, o) in sorted(last_on_stream.items()):
+        ok, hits = wl.verify(b, o)
+        bit_exact = bit_exact and ok
+        matches += hits
+        checked.append({"stream": sidx, "buffer": b, "ok": ok})
+    if dist:
+        t = torch.tensor([1 if bit_exact else 0], dtype=torch.int64,
+                         device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        bit_exact = bool(t.item())
+
+    # ---- dominant kernel's average launch duration: HIP events on its launch stream --------------
     # One stream, launches back to back, one event before the first and one after the last:
-    # (elapsed / launches) is the kernel's duration plus the ~1 us dependent-launch gap, and is
-    # what rocprofv3 --kernel-trace --stats reports for the same command with --streams 1
-    # (profiles/r01_kernel_stats_1stream.csv).  Per-launch event PAIRS are kept as a second
-    # figure; they include ~4 us of launch latency each.
+    # elapsed / launches = the kernel's duration plus the ~1.5 us gap between dependent launches -
+    # what `rocprofv3 --kernel-trace --stats` reports for the same command with --streams 1.
     torch.cuda.synchronize()
-    nk = max(20, min(args.steps, 200))
-    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    nk = max(5, min(args.steps, 200))
     single = [c[:-1] + (cur_stream,) for c in calls]
-    for i in range(10):
+    for i in range(min(10, nk)):
         fn(*single[i % period])
+    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     k0.record()
     for i in range(nk):
         fn(*single[i % period])
     k1.record()
     torch.cuda.synchronize()
-    k_serial_ms = k0.elapsed_time(k1) / nk
-    kms = []
-    for i in range(min(args.steps, 50)):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        fn(*single[i % period])
-        b.record()
-        kms.append((a, b))
-    torch.cuda.synchronize()
-    per_launch = sorted(a.elapsed_time(b) for a, b in kms)
-    k_avg_ms = sum(per_launch) / len(per_launch)
-    k_med_ms = per_launch[len(per_launch) // 2]
-    back_to_back_ms = region_ms / args.steps
+    kernel_ms = k0.elapsed_time(k1) / nk
 
-    # ---- read-bandwidth calibration in the same session -----------------------------
-    sink = torch.zeros(1, dtype=torch.int32, device="cuda")
-    rd = _lib.lib().redgpu_diag_read_dev
-    nb = n * L
-    for i in range(5):
-        rd(exe._h, bufs[i % len(bufs)].data_ptr(), nb, sink.data_ptr(), cur_stream)
-    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    c0.record()
-    for i in range(60):
-        rd(exe._h, bufs[i % len(bufs)].data_ptr(), nb, sink.data_ptr(), cur_stream)
-    c1.record()
-    torch.cuda.synchronize()
-    read_ceiling = 60 * nb / (c0.elapsed_time(c1) * 1e-3) / 1e9
+    # ---- calibrations, same session -------------------------------------------------
+    calib = {}
+    walked = None
+    if rank == 0 and not args.no_calibration:
+        l = _lib.lib()
+        sink = torch.zeros(4, dtype=torch.int32, device="cuda")
+        # (a) streaming-read ceiling: one launch over >= 2 GiB (a 64 MiB launch is mostly ramp)
+        scratch = wl.bufs[0] if wl.bufs[0].numel() >= (1 << 31) else \
+            torch.empty(1 << 31, dtype=torch.uint8, device="cuda").random_(0, 256)
+        nb = scratch.numel() & ~15
+        for _ in range(2):
+            l.redgpu_diag_read_dev(wl.exe._h, scratch.data_ptr(), nb, sink.data_ptr(), cur_stream)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(5):
+            l.redgpu_diag_read_dev(wl.exe._h, scratch.data_ptr(), nb, sink.data_ptr(), cur_stream)
+        c1.record()
+        torch.cuda.synchronize()
+        calib["read_ceiling_GBps"] = round(5 * nb / (c0.elapsed_time(c1) * 1e-3) / 1e9, 1)
+        calib["read_ceiling_how"] = "k_diag_read: 5 launches, each one streaming pass over %d bytes" % nb
+        if scratch is not wl.bufs[0]:
+            del scratch
+        # (b) the same read at the batch's own size (what one launch of this workload can see)
+        if wl.in_bytes < (1 << 31) and not wl.ragged:
+            for i in range(3):
+                l.redgpu_diag_read_dev(wl.exe._h, wl.bufs[i % len(wl.bufs)].data_ptr(),
+                                       wl.in_bytes, sink.data_ptr(), cur_stream)
+            c0.record()
+            for i in range(30):
+                l.redgpu_diag_read_dev(wl.exe._h, wl.bufs[i % len(wl.bufs)].data_ptr(),
+                                       wl.in_bytes, sink.data_ptr(), cur_stream)
+            c1.record()
+            torch.cuda.synchronize()
+            calib["read_at_batch_size_GBps"] = round(30 * wl.in_bytes / (c0.elapsed_time(c1) * 1e-3) / 1e9, 1)
+        # (c) LDS gather roof of a one-lookup-per-byte walk: the walk without its memory side
+        import ctypes as C
+        lookups = C.c_uint64(0)
+        for _ in range(2):
+            l.redgpu_diag_lds_dev(wl.exe._h, 256, sink.data_ptr(), C.byref(lookups), cur_stream)
+        c0.record()
+        for _ in range(5):
+            l.redgpu_diag_lds_dev(wl.exe._h, 256, sink.data_ptr(), C.byref(lookups), cur_stream)
+        c1.record()
+        torch.cuda.synchronize()
+        calib["lds_gather_roof_GBps"] = round(5 * lookups.value / (c0.elapsed_time(c1) * 1e-3) / 1e9, 1)
+        calib["lds_gather_roof_how"] = ("k_diag_lds: %d dependent ds_read_u8 lookups of a 64 KB table per "
+                                        "launch on uniformly random bytes, 4 chains/lane x 512 lanes/CU, "
+                                        "no input traffic; 1 lookup = 1 input byte" % lookups.value)
+        # (d) bytes the walk actually reads (early-exit DFAs)
+        if info["early_death"] or wl.ragged:
+            w = torch.zeros(1, dtype=torch.int64, device="cuda")
+            l.redgpu_diag_walked_dev(wl.exe._h, wl.lead, wl.bufs[0].data_ptr(),
+                                     wl.offsets_dev.data_ptr() if wl.ragged else None,
+                                     0 if wl.ragged else wl.L, n, w.data_ptr(), cur_stream)
+            torch.cuda.synchronize()
+            walked = int(w.item())
 
-    bytes_per_step = n * L
-    out_bytes = n * (4 + 8 + (8 if want_start else 0))
-    value = world * args.steps * bytes_per_step / elapsed / 1e9
-    # roofline: algorithmic input bytes per launch / the kernel's average launch duration
-    # (k_serial_ms above; it still contains the ~1 us gap between dependent launches).
-    kernel_ms = k_serial_ms
-    achieved = bytes_per_step / (kernel_ms * 1e-3) / 1e9
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if world == 1 and args.dfa == "syn256" and want_start and os.path.exists(pmc_path):
-        # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same kernel and
-        # workload (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE; scripts/profile_gpu.sh)
-        traffic = json.load(open(pmc_path)).get("hbm_traffic_bytes_per_launch")
+    # ---- the line ---------------------------------------------------------------------------------
+    value = world * args.steps * wl.in_bytes / elapsed / 1e9
+    l2_bound = info["table_kind"] in (4, 5)  # REDGPU_TAB_GLOBAL_*: one L2 gather per byte
+    algo_bytes = walked if walked is not None else wl.in_bytes
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_config%d_%s.json" % (args.config, wl.dfa_name))
+    if world == 1 and os.path.exists(pmc_path):
+        pj = json.load(open(pmc_path))
+        traffic = pj.get("hbm_traffic_bytes_per_launch")
+        traffic_src = ("%s: separate rocprofv3 --pmc passes of this command (FETCH_SIZE doubled per "
+                       "the gfx950 note + WRITE_SIZE), NOT measured by this run" %
+                       os.path.relpath(pmc_path, ROOT))
+    roofline = {
+        "bound": "l2-gather" if l2_bound else "hbm",
+        "achieved": round(achieved, 1),
+        "peak": L2_PEAK_GLOOKUPS if l2_bound else HBM_PEAK_GBS,
+        "unit": "Glookups/s" if l2_bound else "GB/s",
+        "frac": round(achieved / (L2_PEAK_GLOOKUPS if l2_bound else HBM_PEAK_GBS), 4),
+        "traffic": traffic,
+        "kernel": kernel_name,
+        "algorithmic_bytes_per_launch": algo_bytes,
+        "input_bytes_per_launch": wl.in_bytes,
+        "output_bytes_per_launch": wl.out_bytes - (8 * n if wl.ragged else 0),
+        "kernel_ms": round(kernel_ms, 5),
+        "kernel_ms_how": "HIP events around %d back-to-back launches on one stream (includes the "
+                         "~1.5 us dependent-launch gap)" % nk,
+        "timed_region_ms_per_step": round(region_ms / args.steps, 5),
+    }
+    if traffic_src:
+        roofline["traffic_source"] = traffic_src
+    if l2_bound:
+        roofline["hbm_frac"] = round(wl.in_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        roofline["bound_note"] = ("one dependent gather of the 2 MiB class table per input byte; it "
+                                  "lives in L2 (4 MiB per XCD), whose request rate - 34.5 TB/s / "
+                                  "128 B - caps any one-lookup-per-byte walk at 269.5 GB/s of input")
+    if walked is not None:
+        roofline["bytes_walked_per_launch"] = walked
+        roofline["walked_frac_of_input"] = round(walked / max(1, wl.in_bytes), 4)
+        roofline["scanned_GBps"] = round(wl.in_bytes / (kernel_ms * 1e-3) / 1e9, 1)
+        roofline["algorithmic_note"] = ("achieved counts the bytes the reference's loop consumes "
+                                        "(k_walked); scanned_GBps counts whole lines")
+    roofline.update(calib)
+    shape = ("%d ragged lines of 32..256 B (%.2f GiB)" % (n, wl.in_bytes / 2**30) if wl.ragged else
+             "%d lines x %d B" % (n, wl.L))
     line = {
         "metric": "GB/s input scanned (and Minput/s) for fixed DFA",
         "value": round(value, 2),
@@ -324,40 +549,40 @@ def main():
         "dtype": "u8",
         "data": "synthetic",
         "config": {
-            "workload": "configs[1]: %s DFA (%d states used / %d classes, REDA fmtDirect%d), "
-                        "%d lines x %d B per GPU, match<styLast,false> -> %s" %
-                        (args.dfa, info["states_used"], info["n_classes"], info["format"], n, L,
-                         "result+start+end" if want_start else "result+end"),
-            "lines_per_gpu": n, "line_len": L, "rotating_input_buffers": len(bufs),
+            "workload": "%s: %s DFA (%d states used / %d classes, REDA fmtDirect%d), %s per GPU, "
+                        "match<styLast,%s> -> %s" %
+                        (wl.label, wl.dfa_name, info["states_used"], info["n_classes"],
+                         info["format"], shape, "true" if wl.lead else "false",
+                         "result+start+end" if wl.want_start else "result+end"),
+            "input": "text (47-character alphabet, planted matches)" if wl.text else "uniformly random bytes",
+            "lines_per_gpu": n, "line_len": wl.L if not wl.ragged else "32..256",
+            "rotating_input_buffers": len(wl.bufs),
+            "working_set_bytes": len(wl.bufs) * wl.in_bytes,
             "streams": args.streams,
+            "value_is": ("steps issued round-robin on %d HIP streams: up to %d independent batches in "
+                         "flight" % (args.streams, args.streams)) if args.streams > 1 else
+                        "steps back to back on one stream",
             "sharding": "contiguous shard per GPU, no data-path collective" +
-                        ("; one final RCCL gather of the last step's Outcomes to rank 0"
+                        ("; EVERY step's Outcomes gathered to rank 0 over %s as compact records "
+                         "(pipelined, 2 in flight)" % ("RCCL" if backend == "nccl" else "gloo")
                          if world > 1 else ""),
         },
         "minputs_per_s": round(world * args.steps * n / elapsed / 1e6, 1),
         "bit_exact": bit_exact,
+        "bit_exact_how": wl.verify_note(),
+        "checked": checked,
+        "matches_in_checked": matches,
         "kernel": kernel_name,
-        "roofline": {
-            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "algorithmic_bytes_per_launch": bytes_per_step,
-            "output_bytes_per_launch": out_bytes,
-            "kernel_ms": round(k_serial_ms, 5),
-            "kernel_ms_how": "HIP events around %d back-to-back launches on one stream" % nk,
-            "kernel_ms_event_pair_avg": round(k_avg_ms, 5),
-            "kernel_ms_event_pair_median": round(k_med_ms, 5),
-            "timed_region_ms_per_step": round(back_to_back_ms, 5),
-            "total_traffic_GBps": round((bytes_per_step + out_bytes) / (kernel_ms * 1e-3) / 1e9, 1),
-            "measured_read_ceiling_GBps": round(read_ceiling, 1),
-            "measured_read_ceiling_how": "k_diag_read: 60 back-to-back streaming reads of the "
-                                         "same %d-byte input buffers, one stream" % nb,
-            "lds_roof_GBps": 4400.0,
-            "lds_roof_note": "one ds_read_u8 per byte at 7.0 LDS cycles per 64-lane gather "
-                             "(SQ_LDS_IDX_ACTIVE/SQ_INSTS_LDS), measured 15 us per 64 Mi lookups",
-        },
+        "roofline": roofline,
     }
+    if solo is not None:
+        line["single_gpu_same_workload_GBps"] = round(solo, 1)
+        line["single_gpu_note"] = ("rank 0 alone, untimed phase, same per-GPU workload, no gather: the "
+                                   "weak-scaling reference for this line")
+    if gather is not None:
+        line["gathered_steps"] = gather.finished
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(args, blob, host0)
+        line["cpu_baseline"] = cpu_baseline(args, wl, oracle)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist:

@@ -153,6 +153,56 @@ def gather_outcomes(result, start, end, *, max_result: int, max_line_len: int, d
     return finish
 
 
+def assert_equal_shards(n_local: int, device=None, group=None) -> None:
+    """equal_counts=True skips the count exchange of gather_outcomes: make sure, once, that the
+    promise holds on every rank (a mismatch would hang or corrupt the gather)."""
+    world = dist.get_world_size(group)
+    t = torch.tensor([int(n_local)], dtype=torch.int64, device=device or "cpu")
+    all_n = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(all_n, t, group=group)
+    counts = [int(x.item()) for x in all_n]
+    if any(c != counts[0] for c in counts):
+        raise ValueError("shards differ in size (%s): gather with equal_counts=False" % counts)
+
+
+class StepGather:
+    """Gathers EVERY step's per-line Outcomes to rank 0, pipelined against the scans that follow:
+    push(step outputs) packs the compact records and starts the collective asynchronously; up to
+    `depth` gathers are in flight before the oldest is finished (widened on rank 0).  With RCCL
+    the collective runs on the process group's own stream, so the next step's scan overlaps it.
+    Every shard must have the same size (checked once, collectively, at construction)."""
+
+    def __init__(self, n_local: int, max_result: int, max_line_len: int, with_start: bool,
+                 depth: int = 2, via_host: bool = False, device=None, group=None):
+        self.kw = dict(max_result=max_result, max_line_len=max_line_len, equal_counts=True,
+                       async_op=True, group=group)
+        self.with_start, self.depth, self.via_host = with_start, depth, via_host
+        self.inflight = []
+        self.last = None      # rank 0: the most recently finished step's (result, start, end)
+        self.finished = 0
+        assert_equal_shards(n_local, device=device, group=group)
+
+    def push(self, outputs):
+        r, s, e = outputs
+        if self.via_host:  # gloo rehearsal: records travel through host memory
+            r, e = r.cpu(), e.cpu()
+            s = s.cpu() if s is not None else None
+        self.inflight.append(gather_outcomes(r, s if self.with_start else None, e, **self.kw))
+        while len(self.inflight) > self.depth:
+            self._finish_one()
+
+    def _finish_one(self):
+        got = self.inflight.pop(0)()
+        self.finished += 1
+        if got is not None:
+            self.last = got
+
+    def flush(self):
+        while self.inflight:
+            self._finish_one()
+        return self.last
+
+
 class FinalGather:
     """bench.py helper: remembers the last step's outputs and gathers them once at the end
     (the north-star's "RCCL over xGMI only for the final result gather")."""

@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/prof_r02_c<C>_<D>/ (rocprofv3 CSVs of scripts/profile_r02.sh) into the small
+files kept under profiles/:
+   profiles/r02_kernel_stats_config<C>_<D>[_<run>].csv  rocprofv3 --kernel-trace --stats, verbatim
+   profiles/r02_timeline_config<C>_<D>_<run>.json       span of the dominant kernel's trace (first
+                                                        start -> last end) / launches: the per-step
+                                                        time of overlapped launches, reproducible
+   profiles/r02_pmc_config<C>_<D>.json                  per-launch averages of every PMC counter for
+                                                        the dominant kernel + corrected HBM traffic,
+                                                        LDS busy share, L2 hit rate
+gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports exactly 1/2 of the bytes of a
+wide (16 B/lane) streaming read -> doubled; WRITE_SIZE is exact; both are in KiB."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+SKIP = ("k_diag", "rocclr", "at::", "k_walked", "elementwise", "distribution", "k_pack", "k_unpack")
+
+
+def newest(pattern):
+    found = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return found[-1] if found else None
+
+
+def dominant(stats_csv):
+    best = None
+    for row in csv.DictReader(open(stats_csv)):
+        if any(s in row["Name"] for s in SKIP):
+            continue
+        if best is None or float(row["TotalDurationNs"]) > float(best["TotalDurationNs"]):
+            best = row
+    return best
+
+
+for src in sorted(glob.glob(os.path.join(root, "gpurun_out", "prof_r02_c*"))):
+    tag = os.path.basename(src)[len("prof_r02_c"):]          # e.g. 1_syn256
+    cfg, dfa = tag.split("_", 1)
+    name = "config%s_%s" % (cfg, dfa)
+    dom = None
+    for run in ("stats_1stream", "stats_default"):
+        f = newest(os.path.join(src, run, "*", "*_kernel_stats.csv"))
+        if not f:
+            continue
+        shutil.copy(f, os.path.join(dst, "r02_kernel_stats_%s_%s.csv" % (name, run[6:])))
+        d = dominant(f)
+        if run == "stats_1stream":
+            dom = d
+        tr = newest(os.path.join(src, run, "*", "*_kernel_trace.csv"))
+        if tr and d:
+            rows = [r for r in csv.DictReader(open(tr)) if r["Kernel_Name"] == d["Name"]]
+            rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+            k = len(rows)
+            tail = rows[k // 4:]          # skip warm-up launches and the checker's gaps
+            # longest run of launches without a host-side pause (> 1 ms gap)
+            best, cur = [], []
+            for r in tail:
+                if cur and int(r["Start_Timestamp"]) - int(cur[-1]["End_Timestamp"]) > 1_000_000:
+                    if len(cur) > len(best):
+                        best = cur
+                    cur = []
+                cur.append(r)
+            if len(cur) > len(best):
+                best = cur
+            if len(best) >= 2:
+                span = int(best[-1]["End_Timestamp"]) - int(best[0]["Start_Timestamp"])
+                json.dump({"kernel": d["Name"].split("(redgpu::DevDfa")[0].strip(),
+                           "launches_in_run": len(best), "span_ns": span,
+                           "ns_per_launch_in_span": span / len(best),
+                           "average_kernel_duration_ns": sum(int(r["End_Timestamp"]) -
+                                                             int(r["Start_Timestamp"]) for r in best) / len(best),
+                           "note": "longest back-to-back run of the dominant kernel in the trace: "
+                                   "span / launches is the per-step time when launches overlap"},
+                          open(os.path.join(dst, "r02_timeline_%s_%s.json" % (name, run[6:])), "w"), indent=1)
+    if not dom:
+        continue
+    kname = dom["Name"]
+    summary = {"kernel": kname.split("(redgpu::DevDfa")[0].strip(), "average_ns": float(dom["AverageNs"]),
+               "counters": {}, "launches": {}}
+    for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+        f = newest(os.path.join(d, "*", "*_counter_collection.csv"))
+        if not f:
+            continue
+        agg = collections.defaultdict(list)
+        for row in csv.DictReader(open(f)):
+            if row["Kernel_Name"] == kname:
+                agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
+        for k, v in agg.items():
+            v = v[len(v) // 4:]
+            summary["counters"][k] = sum(v) / len(v)
+            summary["launches"][k] = len(v)
+    c = summary["counters"]
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        summary["hbm_traffic_bytes_per_launch"] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+        summary["hbm_traffic_note"] = ("(2 x FETCH_SIZE + WRITE_SIZE) x 1024: gfx950 FETCH_SIZE counts half "
+                                       "of a 16-B/lane streaming read; separate --pmc passes")
+    if c.get("SQ_INSTS_LDS"):
+        summary["lds_cycles_per_wave_instruction"] = c["SQ_LDS_IDX_ACTIVE"] / c["SQ_INSTS_LDS"]
+        summary["lds_conflict_cycles_per_wave_instruction"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_INSTS_LDS"]
+    if c.get("GRBM_GUI_ACTIVE") and c.get("SQ_LDS_IDX_ACTIVE"):
+        # GRBM_GUI_ACTIVE sums the 8 XCDs' active cycles; LDS cycles are summed over 256 CUs
+        summary["lds_busy_share_of_launch"] = (c["SQ_LDS_IDX_ACTIVE"] / 256) / (c["GRBM_GUI_ACTIVE"] / 8)
+    if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum") is not None and \
+            c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
+        summary["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    if c.get("TCC_REQ_sum"):
+        summary["l2_requests_per_us"] = c["TCC_REQ_sum"] / (float(dom["AverageNs"]) / 1e3)
+    json.dump(summary, open(os.path.join(dst, "r02_pmc_%s.json" % name), "w"), indent=1)
+    print(name, json.dumps({k: v for k, v in summary.items() if k not in ("counters", "launches")}))

@@ -26,6 +26,7 @@
 #include "kernels.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace redgpu {
 
@@ -157,7 +158,14 @@ struct Block4 {
   uint4 p[C][4];  // 64 bytes per chain
 };
 
-template <int MODE, int C>
+// PAIR (lines that are whole 128-byte cache lines): a lane asks for both 64-byte halves of a
+// cache line back to back (the first misses, the second hits the line in L1) instead of coming
+// back for the second half a block's walk later, when L1 has long dropped the line (64-byte
+// blocks on 4 KiB lines: every line fetched from L2 twice, 3.6 against 4.4 TB/s).  Three
+// 64-byte register slots per chain - the half being walked, and the two halves of the NEXT cache
+// line - advance by register moves (48 v_mov per chain per 128 bytes), so the loop body stays
+// two half-blocks long.
+template <int MODE, int C, bool PAIR>
 __global__ void __launch_bounds__(kS4Threads)
 k_stream4(DevDfa d, Batch io) {
   constexpr bool kAcc = MODE == kM4LastStartEnd || MODE == kM4LastEnd;
@@ -190,6 +198,23 @@ k_stream4(DevDfa d, Batch io) {
     for (int k = 0; k < 4; ++k) {
 #pragma unroll
       for (int c = 0; c < C; ++c) blk.p[c][k] = reinterpret_cast<const uint4 *>(p[c])[k];
+    }
+  };
+
+  // both halves of a cache line, chain by chain: the eight requests of one line are adjacent
+  // in the wave's instruction stream (the first misses, seven hit the line in L1) - requested
+  // half by half they are 16 instructions = 128 KB of other lines apart and L1 has dropped it
+  auto issuePair = [&](Block4<C> &h0, Block4<C> &h1, uint64_t tile, uint32_t r, uint32_t second) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      uint64_t ln = tile * kTileLines + uint64_t(c) * 64 + lane;
+      if (ln >= io.n) ln = io.n - 1;
+      const uint8_t *p = io.data + ln * lineLen + uint64_t(r) * 64;
+      const uint8_t *q = p + second;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) h0.p[c][k] = reinterpret_cast<const uint4 *>(p)[k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) h1.p[c][k] = reinterpret_cast<const uint4 *>(q)[k];
     }
   };
 
@@ -234,7 +259,8 @@ k_stream4(DevDfa d, Batch io) {
   uint32_t s[C], accS[C], endv[C], startv[C];
   uint64_t was[C];
 
-  auto walk = [&](const Block4<C> &blk) {
+  auto walk = [&](const Block4<C> &blk, auto storeTag) {
+    constexpr bool STORE = decltype(storeTag)::value;
     if (r == 0) {
 #pragma unroll
       for (int c = 0; c < C; ++c) {
@@ -244,7 +270,14 @@ k_stream4(DevDfa d, Batch io) {
     }
     Book4 b[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) { b[c].acc = accS[c]; b[c].end = 0; b[c].start = 0; }
+    for (int c = 0; c < C; ++c) {
+      b[c].acc = accS[c]; b[c].end = 0; b[c].start = 0;
+      // lane masks carried around the loop feed "s" operands: pinned, or the compiler may park
+      // them in VGPRs ("illegal VGPR to SGPR copy")
+      const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(was[c]));
+      const uint32_t hi = __builtin_amdgcn_readfirstlane(uint32_t(was[c] >> 32));
+      was[c] = (uint64_t(hi) << 32) | lo;
+    }
     uint32_t w[C];
 #define S4_WORD(Q, K, FIELD)                                          \
   _Pragma("unroll") for (int c = 0; c < C; ++c) w[c] = blk.p[c][Q].FIELD; \
@@ -267,8 +300,9 @@ k_stream4(DevDfa d, Batch io) {
         if (wasInit63 && s[c] != init) startv[c] = off + 63;
       }
     }
-    // results after EVERY block, without a branch (k_stream.h): lanes whose line ends here store
-    // into the line's slots, everyone else into the DFA's sink
+    // results after EVERY block that can end a line, without a branch (k_stream.h): lanes whose
+    // line ends here store into the line's slots, everyone else into the DFA's sink
+    if constexpr (!STORE) return;
     const bool lineEnd = r + 1 == R;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -309,17 +343,38 @@ k_stream4(DevDfa d, Batch io) {
     tile = nTile; r = nR;
   };
 
-  for (;;) {
-    next();
-    issue(B, nTile, nR);
-    walk(A);
-    if (!more) break;
-    advance();
-    next();
-    issue(A, nTile, nR);
-    walk(B);
-    if (!more) break;
-    advance();
+  using Yes = std::integral_constant<bool, true>;
+  using No = std::integral_constant<bool, false>;
+  if constexpr (!PAIR) {
+    for (;;) {
+      next();
+      issue(B, nTile, nR);
+      walk(A, Yes{});
+      if (!more) break;
+      advance();
+      next();
+      issue(A, nTile, nR);
+      walk(B, Yes{});
+      if (!more) break;
+      advance();
+    }
+  } else {
+    // A = the half being walked, B / N2 = the halves that follow; (tile, r) = the half in A
+    Block4<C> N2;
+    issue(B, tile, 1);  // the first cache line's second half (its first is in A already)
+    for (;;) {
+      walk(A, No{});    // r even: no line ends here (R is even)
+      r += 1;
+      A = B;
+      // the next cache line: this line's next pair, else the first pair of the wave's next tile
+      next();           // from (tile, r odd): (tile, r + 1) or (next tile, 0) or a re-read
+      issuePair(B, N2, nTile, nR, more ? 64u : 0u);
+      walk(A, Yes{});   // r odd
+      if (!more) break;
+      advance();
+      A = B;
+      B = N2;
+    }
   }
 }
 
@@ -372,8 +427,12 @@ template <int MODE, int C>
 hipError_t launchS4(const DevDfa &d, const Batch &b, const LaunchCfg &cfg, hipStream_t stream) {
   const uint64_t tiles = (b.n + 64 * C - 1) / (64 * C);
   const uint64_t blocks = tiles < uint64_t(cfg.numCUs) ? tiles : uint64_t(cfg.numCUs);
-  hipLaunchKernelGGL((k_stream4<MODE, C>), dim3(uint32_t(blocks)), dim3(kS4Threads), 0, stream, d,
-                     b);
+  if (b.stride % 128 == 0)
+    hipLaunchKernelGGL((k_stream4<MODE, C, true>), dim3(uint32_t(blocks)), dim3(kS4Threads), 0,
+                       stream, d, b);
+  else
+    hipLaunchKernelGGL((k_stream4<MODE, C, false>), dim3(uint32_t(blocks)), dim3(kS4Threads), 0,
+                       stream, d, b);
   return hipGetLastError();
 }
 
@@ -390,15 +449,23 @@ hipError_t launchS4M(int mode, const DevDfa &d, const Batch &b, const LaunchCfg 
 
 }  // namespace
 
-// chains per lane of the fixed-stride hot path: 0 = k_stream.h's two-chain kernel, the default -
-// measured on MI355X (scripts/lab_stream.py, profiles/r02_lab_stream_chains.log): SYN-256, full
-// Outcome, 2 / 3 / 4 chains: 2^20 x 64 B 25.3 / 30.0 / 30.7 us per launch (17.8 / 25.6 / 29.1 on
-// three streams), 2^24 x 64 B 271 / 269 / 269 us (all three at the HBM read + write rate: 84 B
-// of traffic per 64-byte line, 5.2 TB/s), 2^21 x 4 KiB 1.96 / 2.29 / 2.41 ms (64-byte blocks
-// fetch every 128-byte cache line twice).  More chains do fill the LDS queue, but the two-chain
-// kernel already sits on the HBM roof (64-byte lines) and on the LDS gather roof (long lines),
-// and a small batch pays for the bigger first request: 4 chains need 128 KB per CU before the
-// last wave takes its first step.
+// chains per lane of the fixed-stride hot path: 0 = k_stream.h's two-chain kernel, the default.
+// Measured on MI355X (scripts/lab_stream.py; profiles/r02_lab_stream_chains.log), SYN-256, full
+// Outcome, 2 / 3 / 4 chains per lane:
+//   2^20 x 64 B    25.3 / 30.0 / 30.7 us per launch (17.8 / 25.6 / 29.1 on three streams)
+//   2^24 x 64 B    271 / 269 / 269 us: all three at the HBM read + write rate (84 B of traffic per
+//                  64-byte line, 5.2 TB/s)
+//   2^21 x 4 KiB   1.98 / 2.27 / 2.23 ms with the cache-line pairs below (2.29 / 2.41 ms with plain
+//                  64-byte blocks); URI-D on text, where the table gathers do not conflict at all:
+//                  1.96 / - / 2.23 ms
+// So the round-1 reading "LDS only 40-50 % busy => chain-starved" does not hold: twice the chains
+// fill the LDS queue and the launch gets slower.  What a wave has little of is ISSUE slots - every
+// instruction of a wave's in-order stream costs it >= 4 cycles (MI355X_MICROARCH.md, issue cost
+// row), ~9.5 instructions per byte step - and the same 8 waves per CU now carry twice the work per
+// wave, need twice the data before their first step (128 KB per CU at 4 chains) and hold 230
+// VGPRs.  The two-chain kernel sits within 20 % of three roofs at once (LDS gather 5.4 TB/s
+// measured by k_diag_lds below, streaming read 5.7 TB/s, instruction issue ~7 TB/s); this file
+// stays as the measured alternative and as the home of the calibration kernel.
 int stream4Chains() {
   static const int chains = [] {
     const char *e = getenv("REDGPU_STREAM_CHAINS");

@@ -74,6 +74,8 @@ typedef struct redgpu_opts {
 #define REDGPU_F_STREAM_CHAINS_2 128u /* fixed-stride hot path: always the two-chain kernel ... */
 #define REDGPU_F_STREAM_CHAINS_4 256u /* ... or always the four-chain one, whatever the batch size
                                          (default: by batch size; tests, tuning) */
+#define REDGPU_F_FORCE_EARLY 512u /* match: the probe-and-drain kernel of the early-death DFAs for any
+                                    LDS-resident table and any batch size (tests, tuning) */
 #define REDGPU_F_FORCE_HOT     4u /* a table too big for LDS always gets hot rows in LDS, even
                                      when the visit model finds no locality (tests, tuning) */
 

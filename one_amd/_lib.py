@@ -15,7 +15,7 @@ GATHER_PEER, GATHER_RCCL = 0, 1
 DEVICE_CURRENT, DEVICE_NONE = -1, -2
 F_FORCE_GENERIC, F_FORCE_GLOBAL, F_FORCE_HOT, F_NO_BUCKETING, F_FORCE_STREAM = 1, 2, 4, 8, 16
 F_NO_CHUNKING, F_FORCE_CHUNKING = 32, 64
-F_STREAM_CHAINS_2, F_STREAM_CHAINS_4 = 128, 256
+F_STREAM_CHAINS_2, F_STREAM_CHAINS_4, F_FORCE_EARLY = 128, 256, 512
 
 
 class Opts(C.Structure):

@@ -35,6 +35,7 @@ struct DevDfa {
   uint32_t earlyDeath;           // the visit model sees walks die within 16 bytes
   uint32_t tuned;                // hot rows ranked by observed visits
   uint32_t forgetful;            // the walk is mostly in the initial state (k_chunk.h)
+  uint32_t gatherNt;             // REDGPU_GATHER_NT=1: non-temporal table gathers (tuning experiment)
   // start bytes for scan / search (dfa_image.h): packed members, count (0xff = no filter)
   uint32_t startLeadWord, startLeadCount, startFreeWord, startFreeCount;
   uint32_t start2LeadWord, start2LeadCount, start2FreeWord, start2FreeCount;
@@ -62,6 +63,8 @@ struct LaunchCfg {
   int forceStream = 0;  // whole-line kernels even for early-death DFAs (REDGPU_F_FORCE_STREAM)
   int noChunking = 0;   // never cut long lines into speculative chunks (REDGPU_F_NO_CHUNKING)
   int forceChunking = 0; // ... or whenever the shape allows, whatever the DFA (REDGPU_F_FORCE_CHUNKING)
+  int forceEarly = 0;    // k_early for match over any LDS-resident table, whatever the DFA and
+                         // the batch size (REDGPU_F_FORCE_EARLY; tests)
   int streamChains = 0;  // fixed-stride hot path: 0 = by batch size, 2 = k_stream.h always,
                          // 3 / 4 = k_stream4.hip always (REDGPU_F_STREAM_CHAINS_*; tests, tuning)
 };

@@ -80,10 +80,12 @@ template <> struct Tab<REDGPU_TAB_GLOBAL_U16> {
   const uint16_t *t;
   const uint8_t *eq;
   uint32_t nc;
+  uint32_t nt = 0;  // DevDfa::gatherNt: gather with non-temporal loads (tuning experiment)
   __device__ Tab(const uint8_t *tab, const uint8_t *equiv, uint32_t nClasses)
       : t(reinterpret_cast<const uint16_t *>(tab)), eq(equiv), nc(nClasses) {}
   __device__ __forceinline__ uint32_t next(uint32_t s, uint32_t byte) const {
-    return t[size_t(s) * nc + eq[byte]];
+    const uint16_t *p = t + size_t(s) * nc + eq[byte];
+    return nt ? __builtin_nontemporal_load(p) : *p;
   }
 };
 
@@ -168,6 +170,7 @@ __device__ __forceinline__ Tab<KIND> stageTab(const DevDfa &d, uint8_t *lds) {
     tab.nHot = d.nHot;
     tab.shift = d.hotShift;
   }
+  if constexpr (KIND == REDGPU_TAB_GLOBAL_U16) tab.nt = d.gatherNt;
   if constexpr (KIND == REDGPU_TAB_LDS_SPARSE) {
     tab.slot = reinterpret_cast<const uint32_t *>(ldsTab + d.sparseCombOff);
     tab.dflt = d.sparseDefault;
@@ -378,18 +381,24 @@ __device__ int32_t checkLane(const T &tab, const LaneCtx &c, const uint8_t *p, u
   return result;
 }
 
-// include/Matcher.h:413-495
-template <class T>
-__device__ int32_t matchLane(const T &tab, const LaneCtx &c, const uint8_t *p, uint64_t n,
-                             int style, bool lead, uint64_t &startOut, uint64_t &endOut) {
-  startOut = 0;
-  endOut = 0;
-  if (lead && !lookingAt(c, p, 0, n)) return 0;
-  uint32_t s = c.init;
-  int32_t result = c.resultOf(s);
-  int32_t prev = 0;
-  uint64_t matchStart = 0, matchEnd = 0;
-  walkBytes(p, 0, n, [&](uint32_t byte, uint64_t idx) {
+// include/Matcher.h:413-495: the state matchCore's loop carries from byte to byte, resumable -
+// matchLane runs it over a whole line; k_early stops after a few bytes, parks the survivors in
+// LDS and lets other lanes pick them up.
+struct MatchWalk {
+  uint32_t s;
+  int32_t result, prev;
+  uint64_t matchStart, matchEnd;
+  __device__ __forceinline__ void begin(const LaneCtx &c) {
+    s = c.init;
+    result = c.resultOf(s);
+    prev = 0;
+    matchStart = 0;
+    matchEnd = 0;
+  }
+  // one iteration of the loop at :443-479; false = the loop breaks
+  template <class T>
+  __device__ __forceinline__ bool step(const T &tab, const LaneCtx &c, int style, uint32_t byte,
+                                       uint64_t idx) {
     const uint32_t was = s;
     s = tab.next(s, byte);
     if (was == c.init && s != was) matchStart = idx;  // "escaped the initial state" :446-451
@@ -409,13 +418,112 @@ __device__ int32_t matchLane(const T &tab, const LaneCtx &c, const uint8_t *p, u
       if (s < c.nPureDead) return false;
     }
     return true;
-  });
-  if ((style == kStyTangent || style == kStyLast) && result == 0 && prev > 0) result = prev;
-  if (result != 0) {
-    startOut = matchStart;
-    endOut = matchEnd;
   }
-  return result;
+  // the fix-up behind the loop, :481-494
+  __device__ __forceinline__ int32_t finish(int style, uint64_t &startOut, uint64_t &endOut) {
+    startOut = 0;
+    endOut = 0;
+    if ((style == kStyTangent || style == kStyLast) && result == 0 && prev > 0) result = prev;
+    if (result != 0) {
+      startOut = matchStart;
+      endOut = matchEnd;
+    }
+    return result;
+  }
+};
+
+// match<styLast> ("matchLong") alone, lean: what the loop leaves behind is the LAST accepting
+// state, its end and the last "left the initial state" position - result = res[that state] is
+// looked up once at the end instead of at every accept (a dependent global load in the loop), and
+// no style is tested per byte.  Same Outcome as MatchWalk with style == kStyLast: there
+// `prev` is the last accept's result, `result` is 0 or that same value, and finish() returns it.
+struct LastWalk {
+  uint32_t s, accS;
+  uint64_t matchStart, matchEnd;  // matchEnd > 0 <=> some state accepted
+  bool fresh;                     // no byte consumed yet: the Outcome is the initial state's (:435)
+  __device__ __forceinline__ void begin(const LaneCtx &c) {
+    s = c.init;
+    accS = 0;
+    matchStart = 0;
+    matchEnd = 0;
+    fresh = true;
+  }
+  template <class T>
+  __device__ __forceinline__ bool step(const T &tab, const LaneCtx &c, int, uint32_t byte,
+                                       uint64_t idx) {
+    const uint32_t was = s;
+    s = tab.next(s, byte);
+    fresh = false;
+    if (was == c.init && s != was) matchStart = idx;
+    const bool acc = s >= c.firstAccept;
+    if (acc) { accS = s; matchEnd = idx + 1; }
+    return acc || s >= c.nPureDead;
+  }
+  __device__ __forceinline__ int32_t finish(const LaneCtx &c, int, uint64_t &startOut,
+                                            uint64_t &endOut) {
+    // an accepting initial state is only ever reported for an empty input
+    const int32_t r = fresh ? c.resultOf(s) : matchEnd ? c.res[accS] : 0;
+    startOut = r ? matchStart : 0;
+    endOut = r ? matchEnd : 0;
+    return r;
+  }
+  // parked in LDS after at most 255 bytes
+  __device__ __forceinline__ uint4 pack(uint32_t line) const {
+    return make_uint4(line, s | (accS << 16), uint32_t(matchStart) | (uint32_t(matchEnd) << 8), 0u);
+  }
+  __device__ __forceinline__ void unpack(const uint4 &e) {
+    s = e.y & 0xffffu;
+    accS = e.y >> 16;
+    matchStart = e.z & 0xffu;
+    matchEnd = (e.z >> 8) & 0xffu;
+    fresh = false;
+  }
+};
+
+// the general form behind the same interface (any style, tested per byte)
+struct AnyWalk : MatchWalk {
+  __device__ __forceinline__ int32_t finish(const LaneCtx &, int style, uint64_t &startOut,
+                                            uint64_t &endOut) {
+    return MatchWalk::finish(style, startOut, endOut);
+  }
+  __device__ __forceinline__ uint4 pack(uint32_t line) const {
+    return make_uint4(line, s | (uint32_t(matchStart) << 16) | (uint32_t(matchEnd) << 24),
+                      uint32_t(prev), uint32_t(result));
+  }
+  __device__ __forceinline__ void unpack(const uint4 &e) {
+    s = e.y & 0xffffu;
+    matchStart = (e.y >> 16) & 0xffu;
+    matchEnd = e.y >> 24;
+    prev = int32_t(e.z);
+    result = int32_t(e.w);
+  }
+};
+
+template <class T>
+__device__ int32_t matchLane(const T &tab, const LaneCtx &c, const uint8_t *p, uint64_t n,
+                             int style, bool lead, uint64_t &startOut, uint64_t &endOut) {
+  startOut = 0;
+  endOut = 0;
+  if (lead && !lookingAt(c, p, 0, n)) return 0;
+  MatchWalk w;
+  w.begin(c);
+  walkBytes(p, 0, n, [&](uint32_t byte, uint64_t idx) { return w.step(tab, c, style, byte, idx); });
+  return w.finish(style, startOut, endOut);
+}
+
+// match<styLast> through the lean walk: the result table is read once, after the loop - with
+// c.res[s] inside it every accepting step is a second dependent global load on the wave's
+// critical path (a table in L2: two round trips per byte instead of one)
+template <class T>
+__device__ int32_t matchLastLane(const T &tab, const LaneCtx &c, const uint8_t *p, uint64_t n,
+                                 bool lead, uint64_t &startOut, uint64_t &endOut) {
+  startOut = 0;
+  endOut = 0;
+  if (lead && !lookingAt(c, p, 0, n)) return 0;
+  LastWalk w;
+  w.begin(c);
+  walkBytes(p, 0, n, [&](uint32_t byte, uint64_t idx) { return w.step(tab, c, kStyLast, byte, idx); });
+  return w.finish(c, kStyLast, startOut, endOut);
 }
 
 // include/Matcher.h:498-554.  The start positions are visited through walkBytes (16-byte
@@ -659,10 +767,138 @@ k_generic(DevDfa d, Batch b, int style, int lead) {
     } else {
       uint64_t st, en;
       b.result[line] = verb == kSearch ? searchLane(tab, c, p, n, style, lead != 0, st, en)
-                                       : matchLane(tab, c, p, n, style, lead != 0, st, en);
+                       : style == kStyLast ? matchLastLane(tab, c, p, n, lead != 0, st, en)
+                                           : matchLane(tab, c, p, n, style, lead != 0, st, en);
       if (b.start) b.start[line] = st;
       if (b.end) b.end[line] = en;
     }
+  }
+}
+
+// =========================================================================================
+// k_early<KIND>: match<style,doLeader> for EARLY-DEATH DFAs - anchored patterns and signature
+// sets on arbitrary lines (BASELINE configs[3]: LOG-100, matchLong over 8 M ragged lines), where
+// most lines are in a pure dead end after a byte or two and the others walk a whole signature.
+// k_generic gives a lane a line: a wave then holds 64 lines until its slowest one is done (half
+// of its lanes idle on configs[3]) and pays the line's memory round trips - offsets, first
+// bytes, next trip - one behind the other.  Here a workgroup takes 4 lines per lane at a time
+// and
+//   1. PROBES them: offsets and the first 16 bytes of all four lines are requested together, then
+//      each is walked for kEarlyProbe bytes.  A line that is done by then (pure dead end, an
+//      early-exit style, end of line) stores its Outcome; a survivor's loop state (MatchWalk) is
+//      parked in an LDS queue (one wave-aggregated atomic per wave and line slot);
+//   2. DRAINS the queue: the survivors, now dense, are dealt out again - every lane resumes one
+//      at byte kEarlyProbe and walks it to its end.
+// Same lane code as matchLane (MatchWalk::step / finish), so the results are the reference's
+// for every style; the table kinds are the LDS-resident ones.
+// =========================================================================================
+constexpr uint32_t kEarlyProbe = 8;
+constexpr int kEarlyThreads = 512;
+constexpr uint32_t kEarlyLinesPerLane = 4;
+constexpr uint32_t kEarlyChunk = kEarlyThreads * kEarlyLinesPerLane;
+
+template <int KIND, class WALK>
+__global__ void __launch_bounds__(kEarlyThreads)
+k_early(DevDfa d, Batch b, int style, int lead) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const Tab<KIND> tab = stageTab<KIND, kEarlyThreads>(d, lds);
+  uint4 *queue = reinterpret_cast<uint4 *>(lds + 512 + ((ldsTableBytes<KIND>(d) + 15) & ~size_t(15)));
+  __shared__ uint32_t qCount;
+  LaneCtx c;
+  c.eq = lds;
+  c.leader = lds + 256;
+  c.res = d.result;
+  c.init = d.init; c.leaderNext = d.leaderNext; c.nPureDead = d.nPureDead;
+  c.firstAccept = d.firstAccept; c.leaderLen = d.leaderLen;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t nChunks = (b.n + kEarlyChunk - 1) / kEarlyChunk;
+
+  auto lineOf = [&](uint64_t line, const uint8_t *&p, uint64_t &n) {
+    if (b.offsets) {
+      const uint64_t o = b.offsets[line], e = b.offsets[line + 1];
+      p = b.data + o;
+      n = e - o >= b.stride ? e - o - b.stride : 0;  // stride = trailing bytes to drop (ragged)
+    } else {
+      p = b.data + line * b.stride;
+      n = b.stride;
+    }
+  };
+  auto store = [&](uint64_t line, WALK &w) {
+    uint64_t st, en;
+    b.result[line] = w.finish(c, style, st, en);
+    if (b.start) b.start[line] = st;
+    if (b.end) b.end[line] = en;
+  };
+
+  for (uint64_t chunk = blockIdx.x; chunk < nChunks; chunk += gridDim.x) {
+    if (threadIdx.x == 0) qCount = 0;
+    __syncthreads();
+    // ---- 1. probe -------------------------------------------------------------------------
+    const uint8_t *p[kEarlyLinesPerLane];
+    uint64_t n[kEarlyLinesPerLane], line[kEarlyLinesPerLane];
+    uint4 head[kEarlyLinesPerLane];
+#pragma unroll
+    for (uint32_t k = 0; k < kEarlyLinesPerLane; ++k) {
+      line[k] = chunk * kEarlyChunk + uint64_t(k) * kEarlyThreads + threadIdx.x;
+      const uint64_t ln = line[k] < b.n ? line[k] : b.n - 1;
+      lineOf(ln, p[k], n[k]);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kEarlyLinesPerLane; ++k)
+      head[k] = n[k] >= 16 ? *reinterpret_cast<const uint4 *>(p[k]) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (uint32_t k = 0; k < kEarlyLinesPerLane; ++k) {
+      const bool valid = line[k] < b.n;
+      WALK w;
+      w.begin(c);
+      bool alive = valid;
+      if (valid && lead && !lookingAt(c, p[k], 0, n[k])) {
+        b.result[line[k]] = 0;
+        if (b.start) b.start[line[k]] = 0;
+        if (b.end) b.end[line[k]] = 0;
+        alive = false;
+      }
+      if (alive) {
+        if (n[k] >= 16) {
+          const uint32_t words[2] = {head[k].x, head[k].y};
+#pragma unroll
+          for (uint32_t i = 0; i < kEarlyProbe; ++i)
+            if (alive) alive = w.step(tab, c, style, (words[i >> 2] >> (8 * (i & 3))) & 0xffu, i);
+          if (!alive) store(line[k], w);  // done within the probe; the others have bytes left
+        } else {  // a short line: all of it, byte by byte
+          for (uint64_t i = 0; i < n[k] && alive; ++i) alive = w.step(tab, c, style, p[k][i], i);
+          store(line[k], w);
+          alive = false;
+        }
+      }
+      // survivors: one queue slot each, claimed per wave
+      const uint64_t mask = __builtin_amdgcn_ballot_w64(alive);
+      if (mask) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&qCount, uint32_t(__builtin_popcountll(mask)));
+        base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+        if (alive) {
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32),
+                                    __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+          queue[base + rank] = w.pack(uint32_t(line[k]));
+        }
+      }
+    }
+    __syncthreads();
+    // ---- 2. drain -------------------------------------------------------------------------
+    const uint32_t qn = qCount;
+    for (uint32_t q = threadIdx.x; q < qn; q += kEarlyThreads) {
+      const uint4 en = queue[q];
+      WALK w;
+      w.unpack(en);
+      const uint8_t *pp;
+      uint64_t nn;
+      lineOf(en.x, pp, nn);
+      walkBytes(pp, kEarlyProbe, nn,
+                [&](uint32_t byte, uint64_t idx) { return w.step(tab, c, style, byte, idx); });
+      store(en.x, w);
+    }
+    __syncthreads();
   }
 }
 
@@ -1735,6 +1971,30 @@ hipError_t launchGeneric(const DevDfa &d, const Batch &b, int verb, int style, i
 }
 
 template <int KIND>
+hipError_t launchEarlyK(const DevDfa &d, const Batch &b, int style, int lead, const LaunchCfg &cfg,
+                        hipStream_t stream) {
+  const size_t tabBytes = (ldsTableBytes<KIND>(d) + 15) & ~size_t(15);
+  const size_t ldsBytes = 512 + tabBytes + size_t(kEarlyChunk) * 16;
+  hipError_t e = setLds(k_early<KIND, LastWalk>, ldsBytes);
+  if (e == hipSuccess) e = setLds(k_early<KIND, AnyWalk>, ldsBytes);
+  if (e != hipSuccess) return e;
+  // as many workgroups per CU as LDS allows (their probe / drain phases overlap each other's
+  // memory round trips), at most 4
+  uint64_t perCu = (160 * 1024) / (ldsBytes + 256);
+  perCu = perCu < 1 ? 1 : perCu > 4 ? 4 : perCu;
+  const uint64_t chunks = (b.n + kEarlyChunk - 1) / kEarlyChunk;
+  uint64_t blocks = uint64_t(cfg.numCUs) * perCu;
+  if (blocks > chunks) blocks = chunks;
+  if (style == kStyLast)
+    hipLaunchKernelGGL((k_early<KIND, LastWalk>), dim3(uint32_t(blocks)), dim3(kEarlyThreads),
+                       ldsBytes, stream, d, b, style, lead);
+  else
+    hipLaunchKernelGGL((k_early<KIND, AnyWalk>), dim3(uint32_t(blocks)), dim3(kEarlyThreads),
+                       ldsBytes, stream, d, b, style, lead);
+  return hipGetLastError();
+}
+
+template <int KIND>
 hipError_t launchCollectK(const DevDfa &d, const Batch &b, uint64_t cap, uint64_t *counts,
                           const LaunchCfg &cfg, hipStream_t stream) {
   constexpr bool kLds = Tab<KIND>::kInLds || KIND == REDGPU_TAB_HOT_ROWS;
@@ -2083,6 +2343,21 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
   // where the reference's loop stops - measured on ERR 1.3x (64-byte lines) to 38x (4 KiB
   // lines) faster (scripts/bench_anchored.py).
   const bool dying = d.earlyDeath && !cfg.forceStream;
+  // match over an early-death DFA whose table lives in LDS: probe every line for a few bytes,
+  // park the survivors, walk them densely (k_early)
+  const bool earlyKind = d.tableKind == REDGPU_TAB_LDS_FUSED_U8 || d.tableKind == REDGPU_TAB_LDS_FUSED_U16 ||
+                         d.tableKind == REDGPU_TAB_LDS_CLASS_U16 || d.tableKind == REDGPU_TAB_LDS_SPARSE;
+  if (verb == kMatch && earlyKind && !cfg.forceGeneric && b.n < (1ull << 32) && d.nStates <= 65535 &&
+      (cfg.forceEarly || (d.earlyDeath && !cfg.forceStream && b.n >= 16384))) {
+    *kernelName = "k_early<match>";
+    switch (d.tableKind) {
+    case REDGPU_TAB_LDS_FUSED_U8: return launchEarlyK<REDGPU_TAB_LDS_FUSED_U8>(d, b, style, lead, cfg, stream);
+    case REDGPU_TAB_LDS_FUSED_U16: return launchEarlyK<REDGPU_TAB_LDS_FUSED_U16>(d, b, style, lead, cfg, stream);
+    case REDGPU_TAB_LDS_CLASS_U16: return launchEarlyK<REDGPU_TAB_LDS_CLASS_U16>(d, b, style, lead, cfg, stream);
+    default: return launchEarlyK<REDGPU_TAB_LDS_SPARSE>(d, b, style, lead, cfg, stream);
+    }
+  }
+
   // Fixed-stride hot path: check / match, whole 16-byte multiples, 16-byte aligned base.
   // check<.., true> consumes the leader and starts in the post-leader state at byte
   // leaderLen (Matcher.h:370-375); match only peeks it (Matcher.h:424-435).

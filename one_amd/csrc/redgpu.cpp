@@ -4,6 +4,7 @@
 #include "../../include/redgpu.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -49,6 +50,7 @@ int runDev(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint8
                 (dfa->flags & REDGPU_F_FORCE_STREAM) ? 1 : 0,
                 (dfa->flags & REDGPU_F_NO_CHUNKING) ? 1 : 0,
                 (dfa->flags & REDGPU_F_FORCE_CHUNKING) ? 1 : 0,
+                (dfa->flags & REDGPU_F_FORCE_EARLY) ? 1 : 0,
                 (dfa->flags & REDGPU_F_STREAM_CHAINS_2) ? 2
                 : (dfa->flags & REDGPU_F_STREAM_CHAINS_4) ? 4 : 0};
   const char *name = "";
@@ -304,6 +306,10 @@ int uploadImage(SharedImage *im) {
   d.sparseDefault = img.sparseDefault;
   d.tuned = img.tuned ? 1 : 0;
   d.forgetful = img.forgetful ? 1 : 0;
+  {
+    const char *e = getenv("REDGPU_GATHER_NT");
+    d.gatherNt = e && e[0] == '1';
+  }
   d.startLeadWord = img.startLeadWord;
   d.startLeadCount = img.startLeadCount;
   d.startFreeWord = img.startFreeWord;

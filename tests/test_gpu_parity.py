@@ -166,6 +166,72 @@ def test_stream_kernels_two_and_four_chains_vs_oracle(name, stride, n, chains):
             assert np.array_equal(one_amd.check_batch(exe, data, si, 0, stride=stride, n=n), cr)
 
 
+@pytest.mark.parametrize("name", ["log100", "err", "num3", "uri", "newyork", "syn256", "uri_user"])
+def test_probe_and_drain_kernel_vs_oracle(name):
+    """k_early (probe every line for a few bytes, park the survivors in LDS, drain them densely)
+    forced onto every LDS-resident table kind: match, all five styles, with and without the leader,
+    ragged lines (empty, shorter than the probe, shorter than 16 B, long) and fixed strides; plus the
+    default dispatch, which picks it for early-death DFAs on big batches (Matcher.h:413-495)."""
+    blob = load_dfa(name)
+    exe = one_amd.Executable(blob, force_early=True)
+    if exe.info["table_kind"] not in (1, 2, 3, 7):
+        pytest.skip("table not LDS-resident")
+    cpu = O.CpuOracle(blob)
+    heads = {"log100": W.log100_heads(), "err": [b"error", b"erro", b"error in x"],
+             "num3": [b"123abcd ", b"7a", b"55"], "uri": [W.URI_PLANT],
+             "newyork": [b"New York", b"New", b"York"], "syn256": None,
+             "uri_user": [b"https://me@ab.example.com/x "]}[name]
+    n = 20011
+    data, offsets = W.ragged_lines(n, 0, 90, 31, alphabet=(name != "syn256"), heads=heads,
+                                   head_every=2)
+    for si in range(1, 6):
+        for lead in (0, 1):
+            er, es, ee = cpu.batch("match", si, lead, data, offsets=offsets, threads=4)
+            r, s, e = one_amd.match_batch(exe, data, si, lead, offsets=offsets)
+            assert one_amd.last_kernel() == "k_early<match>"
+            assert np.array_equal(r, er), (name, si, lead)
+            assert np.array_equal(s, es) and np.array_equal(e, ee), (name, si, lead)
+    for stride, m in ((64, 9000), (8, 5000), (24, 3001), (256, 2500)):
+        fixed = _fixed_inputs(name, m, stride, seed=stride) if name in (
+            "syn256", "uri", "err", "num3", "newyork") else W.fixed_lines(m, stride, stride)
+        er, es, ee = cpu.batch("match", 4, 1, fixed, stride=stride, n=m, threads=4)
+        r, s, e = one_amd.match_batch(exe, fixed, 4, 1, stride=stride, n=m)
+        assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee), stride
+        r2, _, e2 = one_amd.match_batch(exe, fixed, 5, 0, stride=stride, n=m, want_start=False)
+        er2, _, ee2 = cpu.batch("match", 5, 0, fixed, stride=stride, n=m, threads=4)
+        assert np.array_equal(r2, er2) and np.array_equal(e2, ee2)
+    dflt = one_amd.Executable(blob)
+    if dflt.info["early_death"] and n >= 16384:
+        r, s, e = one_amd.match_batch(dflt, data, 4, 1, offsets=offsets)
+        assert one_amd.last_kernel() == "k_early<match>"
+        er, es, ee = cpu.batch("match", 4, 1, data, offsets=offsets, threads=4)
+        assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee)
+
+
+def test_probe_and_drain_kernel_accepting_initial_state():
+    """The reference reports an accepting INITIAL state only for an empty input (SURVEY 8a-M quirk
+    2: `a*` on "" -> {1,0,0}, on "b" -> {0,0,0}); k_early's lean styLast walk and k_generic's must
+    keep that on batches with empty lines."""
+    blobs = [b for name, fmt, b, _ in kat_items() if name == "quirk_accepting_initial"]
+    assert blobs
+    rng = np.random.default_rng(5)
+    lens = rng.integers(0, 40, 5000)
+    lens[::7] = 0
+    offsets = np.zeros(len(lens) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    data = rng.choice(np.frombuffer(b"aab", dtype=np.uint8), int(offsets[-1]))
+    for blob in blobs:
+        cpu = O.CpuOracle(blob)
+        for kw in (dict(force_early=True), dict(force_generic=True), dict()):
+            exe = one_amd.Executable(blob, **kw)
+            for si in range(1, 6):
+                er, es, ee = cpu.batch("match", si, 0, data, offsets=offsets, threads=2)
+                r, s, e = one_amd.match_batch(exe, data, si, 0, offsets=offsets)
+                assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee), \
+                    (kw, si, one_amd.last_kernel())
+            assert int((er > 0).sum()) > 100
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_dfas_vs_oracle(seed):
     """Synthetic DFAs of every table placement (incl. reachable pure dead ends) vs the oracle."""

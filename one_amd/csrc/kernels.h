@@ -54,6 +54,7 @@ struct Batch {
   uint32_t *state = nullptr; // advance only: per-line StatefulMatcher state, in/out
   const uint32_t *perm = nullptr; // k_ragged only: slot -> line (lines bucketed by length)
   const uint8_t *pad = nullptr;   // k_ragged only: copy of the buffer's last 128 bytes + zeros
+  uint32_t spread = 1;            // k_generic only: one line per `spread` lanes (table in L2)
 };
 
 struct LaunchCfg {

@@ -746,8 +746,11 @@ k_generic(DevDfa d, Batch b, int style, int lead) {
   const uint64_t step = uint64_t(gridDim.x) * kGenericThreads;
   // ragged lines bucketed by length (k_ragged.h): a wave's 64 lines then end together
   const bool usePerm = b.perm && b.perm[b.n] != 0;
-  for (uint64_t idx = uint64_t(blockIdx.x) * kGenericThreads + threadIdx.x; idx < b.n;
-       idx += step) {
+  // Batch::spread > 1 (fewer lines than lanes, table in L2): one line per `spread` lanes - a wave
+  // then gathers 64 / spread table rows per step instead of 64, and more waves share the CU
+  if (b.spread > 1 && (threadIdx.x % b.spread)) return;
+  for (uint64_t idx = (uint64_t(blockIdx.x) * kGenericThreads + threadIdx.x) / b.spread; idx < b.n;
+       idx += step / b.spread) {
     const uint64_t line = usePerm ? b.perm[idx] : idx;
     const uint8_t *p;
     uint64_t n;
@@ -1921,6 +1924,18 @@ hipError_t launchGeneric(const DevDfa &d, const Batch &b, int verb, int style, i
   // an LDS-resident table is re-staged per block: keep the grid near one wave of blocks
   const uint64_t perCu = kLds ? (ldsBytes <= 80 * 1024 ? 2 : 1) : 8;
   const uint64_t cap = uint64_t(cfg.numCUs) * perCu;
+  Batch sb = b;
+  if (!kLds && (verb == kCheck || verb == kMatch)) {
+    // a table in L2 and fewer lines than lanes (BASELINE configs[4]: 65,536 x 64 KiB): spread
+    // the lines over more waves (measured: profiles/r02_spread_syn4k.log)
+    static const int forced = [] { const char *e = getenv("REDGPU_GENERIC_SPREAD"); return e ? atoi(e) : 0; }();
+    uint32_t spread = 1;
+    while (spread < 8 && b.n * (spread * 2) <= cap * kThreads) spread *= 2;
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) spread = uint32_t(forced);
+    else spread = 1;  // default until measured
+    sb.spread = spread;
+    blocks = (b.n * spread + kThreads - 1) / kThreads;
+  }
   if (blocks > cap) blocks = cap;
   if (blocks == 0) blocks = 1;
 #define GEN_LAUNCH(V)                                                                        \
@@ -1955,9 +1970,9 @@ hipError_t launchGeneric(const DevDfa &d, const Batch &b, int verb, int style, i
   }
   // whole-line walks over ragged lines profit from the length bucketing; walks that die in
   // their first bytes (early-death DFAs under check / match) do not care how long the line is
-  Batch pb = b;
+  Batch pb = sb;
   if (b.offsets && !(d.earlyDeath && (verb == kCheck || verb == kMatch))) {
-    hipError_t pe = prepareRagged(b, cfg, stream, false, pb);
+    hipError_t pe = prepareRagged(sb, cfg, stream, false, pb);
     if (pe != hipSuccess) return pe;
   }
   switch (verb) {

@@ -1,0 +1,36 @@
+"""PCIe-inclusive rate of the HOST-buffer entry points (redgpu_match_batch: copy in, kernel, copy
+out, per call), pageable numpy memory as a C++ caller's std::vector would be.  1 thread and 4
+threads sharing one handle.  Developer tool; never bench.py's `value`."""
+import os, sys, threading, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, one_amd
+from one_amd import workloads as W
+from golden_util import load_dfa
+
+exe = one_amd.Executable(load_dfa("syn256"))
+for n, L in ((1 << 20, 64), (1 << 18, 1024), (1 << 18, 4096)):
+    data = W.fixed_lines(n, L, 1, alphabet=False)
+    total = n * L + n * 20
+    for _ in range(2):
+        one_amd.match_batch(exe, data, 4, 0, stride=L, n=n)
+    t0 = time.perf_counter()
+    k = 5
+    for _ in range(k):
+        one_amd.match_batch(exe, data, 4, 0, stride=L, n=n)
+    dt = (time.perf_counter() - t0) / k
+    print("%8d x %5d B host buffers, 1 thread : %8.2f ms/call  %6.1f GB/s of input  (%5.1f GB/s in+out)" %
+          (n, L, dt * 1e3, n * L / dt / 1e9, total / dt / 1e9), flush=True)
+    T = 4
+    shards = [data[i * (n // T) * L:(i + 1) * (n // T) * L] for i in range(T)]
+    def work(i):
+        for _ in range(k):
+            one_amd.match_batch(exe, shards[i], 4, 0, stride=L, n=n // T)
+    for i in range(T): one_amd.match_batch(exe, shards[i], 4, 0, stride=L, n=n // T)
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(T)]
+    t0 = time.perf_counter()
+    for t in ths: t.start()
+    for t in ths: t.join()
+    dt = (time.perf_counter() - t0) / k
+    print("%8d x %5d B host buffers, %d threads: %8.2f ms/batch %6.1f GB/s of input" %
+          (n, L, T, dt * 1e3, n * L / dt / 1e9), flush=True)

@@ -56,28 +56,31 @@ for src in sorted(glob.glob(os.path.join(root, "gpurun_out", "prof_r02_c*"))):
         if tr and d:
             rows = [r for r in csv.DictReader(open(tr)) if r["Kernel_Name"] == d["Name"]]
             rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-            k = len(rows)
-            tail = rows[k // 4:]          # skip warm-up launches and the checker's gaps
-            # longest run of launches without a host-side pause (> 1 ms gap)
-            best, cur = [], []
-            for r in tail:
-                if cur and int(r["Start_Timestamp"]) - int(cur[-1]["End_Timestamp"]) > 1_000_000:
-                    if len(cur) > len(best):
-                        best = cur
+            # runs of launches without a host-side pause (> 1 ms between a start and the latest end)
+            runs, cur, last_end = [], [], 0
+            for r in rows:
+                if cur and int(r["Start_Timestamp"]) - last_end > 1_000_000:
+                    runs.append(cur)
                     cur = []
                 cur.append(r)
-            if len(cur) > len(best):
-                best = cur
-            if len(best) >= 2:
-                span = int(best[-1]["End_Timestamp"]) - int(best[0]["Start_Timestamp"])
-                json.dump({"kernel": d["Name"].split("(redgpu::DevDfa")[0].strip(),
-                           "launches_in_run": len(best), "span_ns": span,
-                           "ns_per_launch_in_span": span / len(best),
-                           "average_kernel_duration_ns": sum(int(r["End_Timestamp"]) -
-                                                             int(r["Start_Timestamp"]) for r in best) / len(best),
-                           "note": "longest back-to-back run of the dominant kernel in the trace: "
-                                   "span / launches is the per-step time when launches overlap"},
-                          open(os.path.join(dst, "r02_timeline_%s_%s.json" % (name, run[6:])), "w"), indent=1)
+                last_end = max(last_end, int(r["End_Timestamp"]))
+            if cur:
+                runs.append(cur)
+            out = []
+            for run_rows in runs:
+                if len(run_rows) < 10:
+                    continue
+                span = max(int(r["End_Timestamp"]) for r in run_rows) - int(run_rows[0]["Start_Timestamp"])
+                avg = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in run_rows) / len(run_rows)
+                out.append({"launches": len(run_rows), "span_ns": span,
+                            "ns_per_launch_in_span": round(span / len(run_rows), 1),
+                            "average_kernel_duration_ns": round(avg, 1),
+                            "overlapped": bool(avg > 1.15 * span / len(run_rows))})
+            json.dump({"kernel": d["Name"].split("(redgpu::DevDfa")[0].strip(), "runs": out,
+                       "note": "runs of the dominant kernel in the trace (split at host pauses > 1 ms): "
+                               "span / launches is the per-step time; in an overlapped run (several "
+                               "streams) it is smaller than the average kernel duration"},
+                      open(os.path.join(dst, "r02_timeline_%s_%s.json" % (name, run[6:])), "w"), indent=1)
     if not dom:
         continue
     kname = dom["Name"]

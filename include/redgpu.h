@@ -18,6 +18,10 @@
  *     doc/Performance.md:81-84, tools/thr_red.cpp:86-91).
  *   - inputs: line i is data[offsets[i], offsets[i+1]) when offsets != NULL (n+1 entries),
  *     else data[i*stride, (i+1)*stride).  Inputs/outputs are caller-owned and never retained.
+ *     A single ragged line of 4 GiB or more: the host-buffer entry points route the batch to
+ *     the general kernel (64-bit positions); through the _dev entry points such a batch must be
+ *     created with REDGPU_F_FORCE_GENERIC (the block-wise kernels keep positions in 32 bits and
+ *     cannot see the offsets before the launch).
  *     Device-pointer (_dev) entry points may read any byte of data[0, offsets[n]) (idle lanes
  *     re-read the first block), so the whole range must be device memory even when
  *     offsets[0] > 0; the host-buffer entry points copy only [offsets[0], offsets[n]).

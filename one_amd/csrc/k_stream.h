@@ -4,7 +4,7 @@
 // bytes, DFA with at most 256 reachable states (fused [state][byte] u8 table, 64 KB, resident
 // at LDS offset 0), styles Last and Full of check / match (include/Matcher.h:363-495).
 //
-// Shape, and why (every number below was measured on MI355X, tools/tune.hip):
+// Shape, and why (every number below was measured on MI355X with the round-1 variant lab, tools/tune.hip in the history up to commit 151617f; scripts/lab_stream.py times the product kernels now):
 //  * One workgroup of 512 threads per CU shares one table copy (8 waves x 2 lines = 16 dependent
 //    chains per CU; 768 and 1024 threads - 3 and 4 waves per SIMD to hide the LDS latency a step
 //    waits for - win only on huge batches of 64-byte lines (2^24 x 64 B: 3.84 against 3.69 TB/s)

@@ -32,7 +32,7 @@ int checkStyle(int style) {
 
 int runDev(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint8_t *data,
            const uint64_t *offsets, uint64_t stride, uint64_t n, int32_t *result,
-           uint64_t *start, uint64_t *end, hipStream_t stream) {
+           uint64_t *start, uint64_t *end, hipStream_t stream, uint32_t extraFlags = 0) {
   if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
   if (dfa->im->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
   if (int rc = checkStyle(style)) return rc;
@@ -45,7 +45,7 @@ int runDev(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint8
   DeviceScope scope(dfa->im->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   Batch b{data, offsets, stride, n, result, start, end};
-  LaunchCfg cfg{dfa->numCUs, (dfa->flags & REDGPU_F_FORCE_GENERIC) ? 1 : 0,
+  LaunchCfg cfg{dfa->numCUs, ((dfa->flags | extraFlags) & REDGPU_F_FORCE_GENERIC) ? 1 : 0,
                 (dfa->flags & REDGPU_F_NO_BUCKETING) ? 1 : 0,
                 (dfa->flags & REDGPU_F_FORCE_STREAM) ? 1 : 0,
                 (dfa->flags & REDGPU_F_NO_CHUNKING) ? 1 : 0,
@@ -62,9 +62,14 @@ int runDev(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint8
 
 // offsets[0..n] of a host-buffer call: monotone (a decreasing pair would underflow a line length
 // on the device and send the walk far outside the buffer)
-int checkOffsets(const uint64_t *offsets, uint64_t n) {
-  for (uint64_t i = 0; i < n; ++i)
+int checkOffsets(const uint64_t *offsets, uint64_t n, uint64_t *maxLen = nullptr) {
+  uint64_t m = 0;
+  for (uint64_t i = 0; i < n; ++i) {
     if (offsets[i] > offsets[i + 1]) return fail(REDGPU_EAPI, "offsets not monotonic");
+    const uint64_t l = offsets[i + 1] - offsets[i];
+    m = l > m ? l : m;
+  }
+  if (maxLen) *maxLen = m;
   return REDGPU_OK;
 }
 
@@ -124,8 +129,12 @@ int runHost(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint
   if (n == 0) return REDGPU_OK;
   if (!result) return fail(REDGPU_EAPI, "null result buffer");
   if (!offsets && stride >= (1ull << 40)) return fail(REDGPU_ELIMIT, "stride too large");
+  uint64_t maxLen = 0;
   if (offsets)
-    if (int rc = checkOffsets(offsets, n)) return rc;
+    if (int rc = checkOffsets(offsets, n, &maxLen)) return rc;
+  // the block-wise ragged kernels keep line positions in 32 bits: a line of 4 GiB or more takes
+  // the general kernel (64-bit positions) - here, where the offsets can be read
+  const uint32_t extra = maxLen >= (1ull << 32) - 256 ? REDGPU_F_FORCE_GENERIC : 0u;
   const uint64_t total = offsets ? offsets[n] : stride * n;
   if (total && !data) return fail(REDGPU_EAPI, "null data buffer");
   DeviceScope scope(dfa->im->device);
@@ -216,7 +225,7 @@ int runHost(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint
       chunkOff = dReb[k];
     }
     const int rc = runDev(dfa, verb, style, doLeader, dData[k], chunkOff, stride, nl, dRes[k],
-                          dStart[k], dEnd[k], s);
+                          dStart[k], dEnd[k], s, extra);
     if (rc != REDGPU_OK) {
       (void)st->sync();
       return rc;

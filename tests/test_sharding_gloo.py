@@ -96,3 +96,70 @@ def test_record_format_roundtrip():
             r2, s2, e2 = fmt.unpack(fmt.pack(res, st if with_start else None, en))
             assert torch.equal(r2, res) and torch.equal(e2, en)
             assert (s2 is None) == (not with_start) and (s2 is None or torch.equal(s2, st))
+
+
+def _worker_steps(rank, world, port, out_path):
+    """Every step's outcomes gathered (StepGather, pipelined) + ragged shards of unequal line
+    counts (balanced by bytes) through gather_outcomes."""
+    import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        blob = load_dfa("uri")
+        cpu = O.CpuOracle(blob)
+        n_per, stride, steps = 700, 64, 5
+        sg = sharding.StepGather(n_per, max_result=1, max_line_len=stride, with_start=True, depth=2)
+        got = []
+        for k in range(steps):
+            data = W.fixed_lines(n_per, stride, 100 + k, plant=W.URI_PLANT,
+                                 first_line=rank * n_per)
+            r, s, e = cpu.batch("match", "last", 0, data, stride=stride, n=n_per)
+            sg.push((torch.from_numpy(r), torch.from_numpy(s.astype(np.int64)),
+                     torch.from_numpy(e.astype(np.int64))))
+            if rank == 0 and sg.last is not None:
+                got.append(tuple(t.clone() for t in sg.last))
+        sg.flush()
+        assert sg.finished == steps
+        last = sg.last
+        # unequal shards are refused up front when equal counts were promised
+        try:
+            sharding.StepGather(n_per + rank, 1, stride, True)
+            mismatch_caught = False
+        except ValueError:
+            mismatch_caught = True
+        assert mismatch_caught
+        # ragged lines: shards by BYTES, unequal line counts, widths by the longest line
+        data, offsets = W.ragged_lines(3001, 1, 900, 77, heads=[W.URI_PLANT], head_every=3)
+        lo, hi = sharding.shard_range_by_bytes(torch.from_numpy(offsets.astype(np.int64)), world, rank)
+        so = offsets[lo:hi + 1]
+        r, s, e = cpu.batch("match", "last", 0, data[int(so[0]):int(so[-1])], offsets=so - so[0])
+        fin = sharding.gather_outcomes(torch.from_numpy(r), torch.from_numpy(s.astype(np.int64)),
+                                       torch.from_numpy(e.astype(np.int64)), max_result=1,
+                                       max_line_len=900)
+        rag = fin()
+        if rank == 0:
+            np.savez(out_path, r=last[0].numpy(), s=last[1].numpy(), e=last[2].numpy(),
+                     rr=rag[0].numpy(), rs=rag[1].numpy(), re=rag[2].numpy(), nshard=hi - lo)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_every_step_gathered_and_ragged_shards_by_bytes(tmp_path):
+    import oracle as O
+    world = 2
+    out = str(tmp_path / "steps.npz")
+    mp.spawn(_worker_steps, args=(world, _free_port(), out), nprocs=world, join=True)
+    g = np.load(out)
+    cpu = O.CpuOracle(load_dfa("uri"))
+    n_per, stride = 700, 64
+    # the last step (seed 104), both ranks' shards in rank order
+    data = W.fixed_lines(n_per * world, stride, 104, plant=W.URI_PLANT)
+    r, s, e = cpu.batch("match", "last", 0, data, stride=stride, n=n_per * world)
+    assert np.array_equal(g["r"], r) and np.array_equal(g["s"].astype(np.uint64), s)
+    assert np.array_equal(g["e"].astype(np.uint64), e)
+    data, offsets = W.ragged_lines(3001, 1, 900, 77, heads=[W.URI_PLANT], head_every=3)
+    r, s, e = cpu.batch("match", "last", 0, data, offsets=offsets)
+    assert np.array_equal(g["rr"], r) and np.array_equal(g["rs"].astype(np.uint64), s)
+    assert np.array_equal(g["re"].astype(np.uint64), e)
+    assert int(g["nshard"]) != 3001 - int(g["nshard"])  # the byte-balanced shards differ in lines

@@ -105,7 +105,7 @@ k_chunk_rewalk(DevDfa d, const uint8_t *data, uint32_t chunkLen, ChunkBufs cb) {
   uint8_t *eq = lds;
   uint8_t *leader = lds + 256;
   const Tab<KIND> tab = stageTab<KIND, kThreads>(d, lds);
-  LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
+  LaneCtx c{eq, leader, resOf<KIND>(d, lds), d.init, d.leaderNext, d.nPureDead, d.firstAccept,
             d.leaderLen};
   const uint32_t cnt = *cb.count;
   const uint64_t step = uint64_t(gridDim.x) * kThreads;
@@ -130,7 +130,7 @@ k_chunk_combine(DevDfa d, Batch b, uint32_t m, uint32_t chunkLen, int style, Chu
   uint8_t *eq = lds;
   uint8_t *leader = lds + 256;
   const Tab<KIND> tab = stageTab<KIND, kThreads>(d, lds);
-  LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
+  LaneCtx c{eq, leader, resOf<KIND>(d, lds), d.init, d.leaderNext, d.nPureDead, d.firstAccept,
             d.leaderLen};
   const uint64_t step = uint64_t(gridDim.x) * kThreads;
   for (uint64_t l = uint64_t(blockIdx.x) * kThreads + threadIdx.x; l < b.n; l += step) {

@@ -143,24 +143,52 @@ template <> struct Tab<REDGPU_TAB_LDS_SPARSE> {
 // What a workgroup stages behind its 512 bytes of equivalence map + leader, and the accessor
 // over it.  Whole table for the LDS kinds, the hot rows for REDGPU_TAB_HOT_ROWS, nothing else.
 template <int KIND>
-__host__ __device__ inline size_t ldsTableBytes(const DevDfa &d) {
+__host__ __device__ inline size_t tableOnlyBytes(const DevDfa &d) {
   if (Tab<KIND>::kInLds) return d.tableBytes;
   if (KIND == REDGPU_TAB_HOT_ROWS) return 65536u;
   return 0;
 }
 
-template <int KIND, int THREADS>
+// The result table (int32 per state) rides along behind the table when it is small enough: the
+// reference reads result() at every accepting state (include/Proxy.h:131-133), and read from
+// global memory that is a dependent L2 round trip inside the loop of every lane function that
+// does (check, scan, search, matchAll, collect, match with the early-exit styles).
+template <int KIND>
+__host__ __device__ inline bool resStaged(const DevDfa &d) {
+  return d.nStates <= 4096 && ((tableOnlyBytes<KIND>(d) + 15) & ~size_t(15)) + size_t(d.nStates) * 4 <=
+                                  size_t(146) * 1024;
+}
+
+template <int KIND>
+__host__ __device__ inline size_t ldsTableBytes(const DevDfa &d) {
+  const size_t t = (tableOnlyBytes<KIND>(d) + 15) & ~size_t(15);
+  return resStaged<KIND>(d) ? t + ((size_t(d.nStates) * 4 + 15) & ~size_t(15)) : t;
+}
+
+// where the lane functions read results: the LDS copy when staged (stageTab), else global memory
+template <int KIND>
+__device__ __forceinline__ const int32_t *resOf(const DevDfa &d, const uint8_t *lds) {
+  return resStaged<KIND>(d) ? reinterpret_cast<const int32_t *>(
+                                  lds + 512 + ((tableOnlyBytes<KIND>(d) + 15) & ~size_t(15)))
+                            : d.result;
+}
+
+template <int KIND, int THREADS, bool WITH_RES = true>
 __device__ __forceinline__ Tab<KIND> stageTab(const DevDfa &d, uint8_t *lds) {
   uint8_t *eq = lds;
   uint8_t *ldsTab = lds + 512;
   for (uint32_t i = threadIdx.x; i < 512 / 4; i += THREADS)
     reinterpret_cast<uint32_t *>(lds)[i] = reinterpret_cast<const uint32_t *>(d.equivLeader)[i];
-  const uint32_t n16 = uint32_t(ldsTableBytes<KIND>(d) / 16);
+  const uint32_t n16 = uint32_t(tableOnlyBytes<KIND>(d) / 16);
   if (n16) {
     const uint4 *src = reinterpret_cast<const uint4 *>(
         d.table + (KIND == REDGPU_TAB_HOT_ROWS ? d.hot8Off : 0u));
     uint4 *dst = reinterpret_cast<uint4 *>(ldsTab);
     for (uint32_t i = threadIdx.x; i < n16; i += THREADS) dst[i] = src[i];
+  }
+  if (WITH_RES && resStaged<KIND>(d)) {
+    int32_t *dst = reinterpret_cast<int32_t *>(ldsTab + ((tableOnlyBytes<KIND>(d) + 15) & ~size_t(15)));
+    for (uint32_t i = threadIdx.x; i < d.nStates; i += THREADS) dst[i] = d.result[i];
   }
   __syncthreads();
   Tab<KIND> tab(Tab<KIND>::kInLds ? ldsTab : d.table, eq, d.nClasses);
@@ -736,7 +764,7 @@ k_generic(DevDfa d, Batch b, int style, int lead) {
   uint8_t *eq = lds;
   uint8_t *leader = lds + 256;
   const Tab<KIND> tab = stageTab<KIND, kGenericThreads>(d, lds);
-  LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
+  LaneCtx c{eq, leader, resOf<KIND>(d, lds), d.init, d.leaderNext, d.nPureDead, d.firstAccept,
             d.leaderLen};
   c.startWord[0] = d.startFreeWord; c.startCount[0] = d.startFreeCount;
   c.startWord[1] = d.startLeadWord; c.startCount[1] = d.startLeadCount;
@@ -797,15 +825,26 @@ k_generic(DevDfa d, Batch b, int style, int lead) {
 // =========================================================================================
 constexpr uint32_t kEarlyProbe = 8;
 constexpr int kEarlyThreads = 512;
-constexpr uint32_t kEarlyLinesPerLane = 4;
-constexpr uint32_t kEarlyChunk = kEarlyThreads * kEarlyLinesPerLane;
 
-template <int KIND, class WALK>
-__global__ void __launch_bounds__(kEarlyThreads)
+// LPL = lines per lane and round; WPS = waves per SIMD the register allocation must allow: LDS
+// decides how many workgroups share a CU, and occupancy is what this kernel lives on.  Measured on
+// configs[3] (2^23 lines, LOG-100; scripts/gpu_run10.sh): 4 lines per lane, 2 workgroups per CU
+// 443 us; 2 lines per lane, 3 workgroups per CU 415 us; 1 line, 3 workgroups 437 us.  Requesting
+// the next round's offsets and first bytes a phase ahead, and draining two survivors per lane with
+// their next 64 bytes requested together, both made it slower (446-569 us: more registers, and
+// the launch moves ~2.2 GB through L2 - nearly every cache line of the input is touched by a line
+// start, and again when a survivor is drained - so it sits near the memory system's rate for
+// scattered 128-byte requests, not on the latency of any one of them).
+template <int KIND, class WALK, int LPL, int WPS>
+__global__ void __launch_bounds__(kEarlyThreads, WPS)
 k_early(DevDfa d, Batch b, int style, int lead) {
+  constexpr uint32_t kEarlyChunk = kEarlyThreads * LPL;
+  constexpr uint32_t L = LPL;
   extern __shared__ __align__(16) uint8_t lds[];
-  const Tab<KIND> tab = stageTab<KIND, kEarlyThreads>(d, lds);
-  uint4 *queue = reinterpret_cast<uint4 *>(lds + 512 + ((ldsTableBytes<KIND>(d) + 15) & ~size_t(15)));
+  // (no LDS copy of the result table: this kernel reads it once per line, and the space buys a
+  // third workgroup per CU)
+  const Tab<KIND> tab = stageTab<KIND, kEarlyThreads, false>(d, lds);
+  uint4 *queue = reinterpret_cast<uint4 *>(lds + 512 + ((tableOnlyBytes<KIND>(d) + 15) & ~size_t(15)));
   __shared__ uint32_t qCount;
   LaneCtx c;
   c.eq = lds;
@@ -816,13 +855,16 @@ k_early(DevDfa d, Batch b, int style, int lead) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t nChunks = (b.n + kEarlyChunk - 1) / kEarlyChunk;
 
-  auto lineOf = [&](uint64_t line, const uint8_t *&p, uint64_t &n) {
+  // line -> (byte offset, length); lines past the end of the batch read the last line (never
+  // stored: `valid` below)
+  auto spanOf = [&](uint64_t line, uint64_t &o, uint64_t &n) {
+    const uint64_t ln = line < b.n ? line : b.n - 1;
     if (b.offsets) {
-      const uint64_t o = b.offsets[line], e = b.offsets[line + 1];
-      p = b.data + o;
+      o = b.offsets[ln];
+      const uint64_t e = b.offsets[ln + 1];
       n = e - o >= b.stride ? e - o - b.stride : 0;  // stride = trailing bytes to drop (ragged)
     } else {
-      p = b.data + line * b.stride;
+      o = ln * b.stride;
       n = b.stride;
     }
   };
@@ -836,29 +878,27 @@ k_early(DevDfa d, Batch b, int style, int lead) {
   for (uint64_t chunk = blockIdx.x; chunk < nChunks; chunk += gridDim.x) {
     if (threadIdx.x == 0) qCount = 0;
     __syncthreads();
-    // ---- 1. probe -------------------------------------------------------------------------
-    const uint8_t *p[kEarlyLinesPerLane];
-    uint64_t n[kEarlyLinesPerLane], line[kEarlyLinesPerLane];
-    uint4 head[kEarlyLinesPerLane];
+    // ---- 1. probe: offsets and first bytes of all the lane's lines requested together --------
+    uint64_t o[L], n[L];
+    uint4 head[L];
 #pragma unroll
-    for (uint32_t k = 0; k < kEarlyLinesPerLane; ++k) {
-      line[k] = chunk * kEarlyChunk + uint64_t(k) * kEarlyThreads + threadIdx.x;
-      const uint64_t ln = line[k] < b.n ? line[k] : b.n - 1;
-      lineOf(ln, p[k], n[k]);
-    }
+    for (uint32_t k = 0; k < L; ++k)
+      spanOf(chunk * kEarlyChunk + uint64_t(k) * kEarlyThreads + threadIdx.x, o[k], n[k]);
 #pragma unroll
-    for (uint32_t k = 0; k < kEarlyLinesPerLane; ++k)
-      head[k] = n[k] >= 16 ? *reinterpret_cast<const uint4 *>(p[k]) : make_uint4(0, 0, 0, 0);
+    for (uint32_t k = 0; k < L; ++k)
+      head[k] = n[k] >= 16 ? *reinterpret_cast<const uint4 *>(b.data + o[k]) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (uint32_t k = 0; k < kEarlyLinesPerLane; ++k) {
-      const bool valid = line[k] < b.n;
+    for (uint32_t k = 0; k < L; ++k) {
+      const uint64_t line = chunk * kEarlyChunk + uint64_t(k) * kEarlyThreads + threadIdx.x;
+      const bool valid = line < b.n;
+      const uint8_t *p = b.data + o[k];
       WALK w;
       w.begin(c);
       bool alive = valid;
-      if (valid && lead && !lookingAt(c, p[k], 0, n[k])) {
-        b.result[line[k]] = 0;
-        if (b.start) b.start[line[k]] = 0;
-        if (b.end) b.end[line[k]] = 0;
+      if (valid && lead && !lookingAt(c, p, 0, n[k])) {
+        b.result[line] = 0;
+        if (b.start) b.start[line] = 0;
+        if (b.end) b.end[line] = 0;
         alive = false;
       }
       if (alive) {
@@ -867,10 +907,10 @@ k_early(DevDfa d, Batch b, int style, int lead) {
 #pragma unroll
           for (uint32_t i = 0; i < kEarlyProbe; ++i)
             if (alive) alive = w.step(tab, c, style, (words[i >> 2] >> (8 * (i & 3))) & 0xffu, i);
-          if (!alive) store(line[k], w);  // done within the probe; the others have bytes left
+          if (!alive) store(line, w);  // done within the probe; the others have bytes left
         } else {  // a short line: all of it, byte by byte
-          for (uint64_t i = 0; i < n[k] && alive; ++i) alive = w.step(tab, c, style, p[k][i], i);
-          store(line[k], w);
+          for (uint64_t i = 0; i < n[k] && alive; ++i) alive = w.step(tab, c, style, p[i], i);
+          store(line, w);
           alive = false;
         }
       }
@@ -883,23 +923,23 @@ k_early(DevDfa d, Batch b, int style, int lead) {
         if (alive) {
           const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32),
                                     __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
-          queue[base + rank] = w.pack(uint32_t(line[k]));
+          queue[base + rank] = w.pack(uint32_t(k * kEarlyThreads + threadIdx.x));
         }
       }
     }
     __syncthreads();
-    // ---- 2. drain -------------------------------------------------------------------------
+    // ---- 2. drain: the survivors, dense again, walked to their end ---------------------------
     const uint32_t qn = qCount;
     for (uint32_t q = threadIdx.x; q < qn; q += kEarlyThreads) {
       const uint4 en = queue[q];
       WALK w;
       w.unpack(en);
-      const uint8_t *pp;
-      uint64_t nn;
-      lineOf(en.x, pp, nn);
-      walkBytes(pp, kEarlyProbe, nn,
+      const uint64_t ln = chunk * kEarlyChunk + (en.x & 0xfffu);
+      uint64_t oo, nl;
+      spanOf(ln, oo, nl);
+      walkBytes(b.data + oo, kEarlyProbe, nl,
                 [&](uint32_t byte, uint64_t idx) { return w.step(tab, c, style, byte, idx); });
-      store(en.x, w);
+      store(ln, w);
     }
     __syncthreads();
   }
@@ -964,7 +1004,7 @@ k_scan_marked(DevDfa d, Batch b, int style, int lead) {
   uint32_t *candK = reinterpret_cast<uint32_t *>(lineOff + kThreads);  // scan with the leader
   uint32_t *lineFirst = candK + kThreads;   // where a line's candidates start in the list
   uint32_t *waveTot = lineFirst + kThreads;  // candidates per wave (block-wide prefix sum)
-  LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
+  LaneCtx c{eq, leader, resOf<KIND>(d, lds), d.init, d.leaderNext, d.nPureDead, d.firstAccept,
             d.leaderLen};
   // The batch's candidates are SPREAD over the threads, one each, instead of every lane visiting
   // its own line's one after the other: a wave then runs visit() once, not once per candidate
@@ -1393,7 +1433,7 @@ k_collect(DevDfa d, Batch b, uint64_t cap, uint64_t *counts) {
   uint8_t *eq = lds;
   uint8_t *leader = lds + 256;
   const Tab<KIND> tab = stageTab<KIND, kThreads>(d, lds);
-  LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
+  LaneCtx c{eq, leader, resOf<KIND>(d, lds), d.init, d.leaderNext, d.nPureDead, d.firstAccept,
             d.leaderLen};
   c.startWord[0] = d.startFreeWord; c.startCount[0] = d.startFreeCount;
   c.startWord[1] = d.startLeadWord; c.startCount[1] = d.startLeadCount;
@@ -1477,7 +1517,7 @@ k_matchall(DevDfa d, Batch b, uint64_t cap, uint64_t *counts, int lead) {
   uint8_t *eq = lds;
   uint8_t *leader = lds + 256;
   const Tab<KIND> tab = stageTab<KIND, kThreads>(d, lds);
-  LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
+  LaneCtx c{eq, leader, resOf<KIND>(d, lds), d.init, d.leaderNext, d.nPureDead, d.firstAccept,
             d.leaderLen};
   c.startWord[0] = d.startFreeWord; c.startCount[0] = d.startFreeCount;
   c.startWord[1] = d.startLeadWord; c.startCount[1] = d.startLeadCount;
@@ -1514,7 +1554,7 @@ k_advance(DevDfa d, Batch b, uint32_t *state) {
   uint8_t *eq = lds;
   uint8_t *leader = lds + 256;
   const Tab<KIND> tab = stageTab<KIND, kThreads>(d, lds);
-  LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
+  LaneCtx c{eq, leader, resOf<KIND>(d, lds), d.init, d.leaderNext, d.nPureDead, d.firstAccept,
             d.leaderLen};
   c.startWord[0] = d.startFreeWord; c.startCount[0] = d.startFreeCount;
   c.startWord[1] = d.startLeadWord; c.startCount[1] = d.startLeadCount;
@@ -1608,7 +1648,7 @@ k_replace(DevDfa d, Batch b, int style, int lead, const uint8_t *repl, uint64_t 
   uint8_t *eq = lds;
   uint8_t *leader = lds + 256;
   const Tab<KIND> tab = stageTab<KIND, kThreads>(d, lds);
-  LaneCtx c{eq, leader, d.result, d.init, d.leaderNext, d.nPureDead, d.firstAccept,
+  LaneCtx c{eq, leader, resOf<KIND>(d, lds), d.init, d.leaderNext, d.nPureDead, d.firstAccept,
             d.leaderLen};
   c.startWord[0] = d.startFreeWord; c.startCount[0] = d.startFreeCount;
   c.startWord[1] = d.startLeadWord; c.startCount[1] = d.startLeadCount;
@@ -1740,7 +1780,7 @@ k_walked(DevDfa d, Batch b, int lead, unsigned long long *walked) {
   LaneCtx c;
   c.eq = lds;
   c.leader = lds + 256;
-  c.res = d.result;
+  c.res = resOf<KIND>(d, lds);
   c.init = d.init; c.leaderNext = d.leaderNext; c.nPureDead = d.nPureDead;
   c.firstAccept = d.firstAccept; c.leaderLen = d.leaderLen;
   const uint64_t step = uint64_t(gridDim.x) * kThreads;
@@ -1985,28 +2025,33 @@ hipError_t launchGeneric(const DevDfa &d, const Batch &b, int verb, int style, i
   return hipGetLastError();
 }
 
+template <int KIND, class WALK, int LPL, int WPS>
+hipError_t launchEarlyV(const DevDfa &d, const Batch &b, int style, int lead, const LaunchCfg &cfg,
+                        hipStream_t stream) {
+  const size_t tabBytes = (tableOnlyBytes<KIND>(d) + 15) & ~size_t(15);
+  const size_t ldsBytes = 512 + tabBytes + size_t(kEarlyThreads) * LPL * 16;
+  hipError_t e = setLds(k_early<KIND, WALK, LPL, WPS>, ldsBytes);
+  if (e != hipSuccess) return e;
+  // as many workgroups per CU as LDS and the register budget allow (their probe / drain phases
+  // overlap each other's memory round trips)
+  uint64_t perCu = (160 * 1024) / (ldsBytes + 256);
+  const uint64_t byRegs = uint64_t(WPS) * 4 / (kEarlyThreads / 64);
+  perCu = perCu > byRegs ? byRegs : perCu;
+  if (perCu < 1) perCu = 1;
+  const uint64_t chunk = uint64_t(kEarlyThreads) * LPL;
+  const uint64_t chunks = (b.n + chunk - 1) / chunk;
+  uint64_t blocks = uint64_t(cfg.numCUs) * perCu;
+  if (blocks > chunks) blocks = chunks;
+  hipLaunchKernelGGL((k_early<KIND, WALK, LPL, WPS>), dim3(uint32_t(blocks)), dim3(kEarlyThreads),
+                     ldsBytes, stream, d, b, style, lead);
+  return hipGetLastError();
+}
+
 template <int KIND>
 hipError_t launchEarlyK(const DevDfa &d, const Batch &b, int style, int lead, const LaunchCfg &cfg,
                         hipStream_t stream) {
-  const size_t tabBytes = (ldsTableBytes<KIND>(d) + 15) & ~size_t(15);
-  const size_t ldsBytes = 512 + tabBytes + size_t(kEarlyChunk) * 16;
-  hipError_t e = setLds(k_early<KIND, LastWalk>, ldsBytes);
-  if (e == hipSuccess) e = setLds(k_early<KIND, AnyWalk>, ldsBytes);
-  if (e != hipSuccess) return e;
-  // as many workgroups per CU as LDS allows (their probe / drain phases overlap each other's
-  // memory round trips), at most 4
-  uint64_t perCu = (160 * 1024) / (ldsBytes + 256);
-  perCu = perCu < 1 ? 1 : perCu > 4 ? 4 : perCu;
-  const uint64_t chunks = (b.n + kEarlyChunk - 1) / kEarlyChunk;
-  uint64_t blocks = uint64_t(cfg.numCUs) * perCu;
-  if (blocks > chunks) blocks = chunks;
-  if (style == kStyLast)
-    hipLaunchKernelGGL((k_early<KIND, LastWalk>), dim3(uint32_t(blocks)), dim3(kEarlyThreads),
-                       ldsBytes, stream, d, b, style, lead);
-  else
-    hipLaunchKernelGGL((k_early<KIND, AnyWalk>), dim3(uint32_t(blocks)), dim3(kEarlyThreads),
-                       ldsBytes, stream, d, b, style, lead);
-  return hipGetLastError();
+  if (style != kStyLast) return launchEarlyV<KIND, AnyWalk, 2, 4>(d, b, style, lead, cfg, stream);
+  return launchEarlyV<KIND, LastWalk, 2, 6>(d, b, style, lead, cfg, stream);
 }
 
 template <int KIND>
@@ -2363,6 +2408,7 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
   const bool earlyKind = d.tableKind == REDGPU_TAB_LDS_FUSED_U8 || d.tableKind == REDGPU_TAB_LDS_FUSED_U16 ||
                          d.tableKind == REDGPU_TAB_LDS_CLASS_U16 || d.tableKind == REDGPU_TAB_LDS_SPARSE;
   if (verb == kMatch && earlyKind && !cfg.forceGeneric && b.n < (1ull << 32) && d.nStates <= 65535 &&
+      size_t(d.tableBytes) + 512 + 16384 + 1024 <= size_t(160) * 1024 &&
       (cfg.forceEarly || (d.earlyDeath && !cfg.forceStream && b.n >= 16384))) {
     *kernelName = "k_early<match>";
     switch (d.tableKind) {

@@ -106,6 +106,10 @@ for case in range(cases):
                   ("no_bucketing", 0.2), ("force_stream", 0.3), ("force_chunking", 0.3))):
         if rng.random() < p:
             flags[f] = True
+    if rng.random() < 0.25:
+        flags["force_early"] = True        # k_early for match over any LDS-resident table
+    if rng.random() < 0.3:
+        flags["stream_chains"] = int(rng.choice([2, 4]))  # k_stream / k_stream4 whatever the size
     if rng.random() < 0.3 and not CLS_BIAS:
         flags["lds_table_max"] = int(rng.choice([8 * 256, 40 * 256, 100 * 256, 20000, 70000]))
     try:

@@ -1272,6 +1272,21 @@ def test_match_all_on_gpu():
     mask = np.arange(4)[None, :] < np.minimum(exp[0], 4).astype(np.int64)[:, None]
     for g, e in zip(got[1:], exp[1:]):
         assert np.array_equal(g[mask], e[mask])
+    # small capacities keep their records in registers (cap <= 4), larger ones store as they go
+    rdata, roffs = W.ragged_lines(4000, 0, 120, 12, alphabet=False)
+    for name2 in ("syn256", "uri"):
+        blob2 = load_dfa(name2)
+        exe2, cpu2 = one_amd.Executable(blob2), O.CpuOracle(blob2)
+        d2, o2 = (rdata, roffs) if name2 == "syn256" else W.ragged_lines(
+            4000, 0, 200, 13, heads=[W.URI_PLANT, b"x " + W.URI_PLANT + W.URI_PLANT], head_every=2)
+        for cap2 in (1, 2, 3, 4, 6):
+            for lead in (True, False):
+                got = one_amd.match_all_batch(exe2, d2, cap2, lead, offsets=o2)
+                exp = cpu2.match_all_batch(d2, cap2, do_leader=lead, offsets=o2)
+                assert np.array_equal(got[0], exp[0]), (name2, cap2)
+                mask = np.arange(cap2)[None, :] < np.minimum(exp[0], cap2).astype(np.int64)[:, None]
+                for g, e in zip(got[1:], exp[1:]):
+                    assert np.array_equal(g[mask], e[mask]), (name2, cap2, lead)
 
 
 def test_stateful_matcher_on_gpu():

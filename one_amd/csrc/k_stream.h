@@ -425,6 +425,9 @@ k_stream(DevDfa d, Batch io) {
   }
   const int32_t myRes = IDXD ? 0 : threadIdx.x < d.nStates ? d.result[threadIdx.x] : 0;
   BlockRegs<HALVES> A[CH], B[CH];
+  // (Tried, round 2: holding wave w's first requests back by w x 64..1024 cycles, so that the
+  // waves' first blocks arrive one after the other instead of together at the end of the first
+  // 32 MB: 25.5-26.5 us against 25.9 us - no effect.)
   if (EARLY) issue(A);
   {
     uint4 *dst = reinterpret_cast<uint4 *>(tab);

@@ -481,6 +481,29 @@ def main():
         calib["lds_gather_roof_how"] = ("k_diag_lds: %d dependent ds_read_u8 lookups of a 64 KB table per "
                                         "launch on uniformly random bytes, 4 chains/lane x 512 lanes/CU, "
                                         "no input traffic; 1 lookup = 1 input byte" % lookups.value)
+        # (c2) the same kernel on 16 x the batch in ONE launch: what it sustains once a launch's head
+        # (table staging, first blocks arriving) and tail (the last lines' dependent steps) are
+        # amortised - the gap to `achieved` is what a 64 MiB launch loses to them
+        if args.config == 1 and wl.in_bytes <= (1 << 27):
+            big_n = n * 16
+            big = torch.empty(big_n * wl.L, dtype=torch.uint8, device="cuda").random_(0, 256)
+            br = torch.empty(big_n, dtype=torch.int32, device="cuda")
+            bs = torch.empty(big_n, dtype=torch.int64, device="cuda") if wl.want_start else None
+            be = torch.empty(big_n, dtype=torch.int64, device="cuda")
+            targs = (wl.exe._h, wl.style, wl.lead, big.data_ptr(), None, wl.L, big_n, br.data_ptr(),
+                     bs.data_ptr() if bs is not None else None, be.data_ptr(), cur_stream)
+            for _ in range(2):
+                fn(*targs)
+            c0.record()
+            for _ in range(5):
+                fn(*targs)
+            c1.record()
+            torch.cuda.synchronize()
+            calib["kernel_at_16x_batch_GBps"] = round(5 * big_n * wl.L / (c0.elapsed_time(c1) * 1e-3) / 1e9, 1)
+            calib["kernel_at_16x_batch_how"] = ("the same entry point, %d lines x %d B of random bytes in one "
+                                                "launch (not the workload: shows the launch's head + tail)" %
+                                                (big_n, wl.L))
+            del big, br, bs, be
         # (d) bytes the walk actually reads (early-exit DFAs)
         if info["early_death"] or wl.ragged:
             w = torch.zeros(1, dtype=torch.int64, device="cuda")

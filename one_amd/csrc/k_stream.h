@@ -682,13 +682,8 @@ hipError_t launchStreamTT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
 template <int MODE>
 hipError_t launchStreamT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
                          hipStream_t stream) {
-  static const int threads = [] {
-    const char *e = getenv("REDGPU_STREAM_THREADS");  // tuning knob; default 512
-    const int v = e ? atoi(e) : kStreamThreads;
-    return (v == 256 || v == 1024) ? v : 512;
-  }();
-  if (threads == 256 || (threads == 512 && fewLines(b, cfg)))
-    return launchStreamTT<MODE, 256>(d, b, cfg, stream);
-  if (threads == 1024) return launchStreamTT<MODE, 1024>(d, b, cfg, stream);
+  // (a 1024-thread form existed behind REDGPU_STREAM_THREADS in round 1 and lost at every shape
+  // but 2^24 x 64 B: 26.8 against 24.7 us on configs[1], 3.45 against 4.25 TB/s on 4 KiB lines)
+  if (fewLines(b, cfg)) return launchStreamTT<MODE, 256>(d, b, cfg, stream);
   return launchStreamTT<MODE, 512>(d, b, cfg, stream);
 }

@@ -136,6 +136,18 @@ hipError_t launchDiagLds(const DevDfa &dfa, uint32_t rounds, uint32_t *sink, int
 hipError_t launchWalked(const DevDfa &dfa, const Batch &b, int doLeader, unsigned long long *walked,
                         const LaunchCfg &cfg, hipStream_t stream);
 
+// launchBatch's / launchAdvance's kernel families, one translation unit each (kernels.hip is
+// compiled per family, -DREDGPU_TU): *handled = false when the batch is not the family's.
+hipError_t launchFixedFamily(const DevDfa &dfa, const Batch &b, int verb, int style, int doLeader,
+                             const LaunchCfg &cfg, hipStream_t stream, const char **kernelName,
+                             bool *handled);
+hipError_t launchRaggedFamily(const DevDfa &dfa, const Batch &b, int verb, int style, int doLeader,
+                              const LaunchCfg &cfg, hipStream_t stream, const char **kernelName,
+                              bool *handled);
+hipError_t launchAdvanceStream(const DevDfa &dfa, const Batch &b, uint32_t *state,
+                               const LaunchCfg &cfg, hipStream_t stream, const char **kernelName,
+                               bool *handled);
+
 // True when the specialised fixed-stride kernels can run this DFA at all.
 bool fastPathEligible(const DevDfa &dfa);
 

@@ -31,6 +31,17 @@
 
 #include "../../include/redgpu.h"
 
+// This file is compiled three times in parallel (Makefile: -DREDGPU_TU=1/2/3): the templates are
+// instantiated where their launchers are CALLED, so each translation unit only pays for one
+// family of kernels - 1 = the fixed-stride family (k_stream, k_chunk, k_fixed), 2 = k_ragged,
+// 3 = everything else and the dispatch.  REDGPU_TU undefined or 0 = all of it in one unit.
+#ifndef REDGPU_TU
+#define REDGPU_TU 0
+#endif
+#define REDGPU_TU_STREAM (REDGPU_TU == 0 || REDGPU_TU == 1)
+#define REDGPU_TU_RAGGED (REDGPU_TU == 0 || REDGPU_TU == 2)
+#define REDGPU_TU_GENERIC (REDGPU_TU == 0 || REDGPU_TU == 3)
+
 namespace redgpu {
 
 namespace {
@@ -2176,22 +2187,294 @@ hipError_t launchFixedS(int style, const DevDfa &d, const Batch &b, uint32_t sta
 } // namespace
 
 // REDGPU_TAB_HOT_ROWS DFAs whose hot set the streaming kernel can index with one byte
-static bool hotStreamEligible(const DevDfa &d) {
+[[maybe_unused]] static bool hotStreamEligible(const DevDfa &d) {
   return d.tableKind == REDGPU_TAB_HOT_ROWS && d.nHot > 0 && d.hot8Off != 0 &&
          d.deadAbsorbing;
 }
 
 // DFAs of more than 256 states with a class table of at most 64 KB: k_stream's class-table form
-static bool clsStreamEligible(const DevDfa &d) {
+[[maybe_unused]] static bool clsStreamEligible(const DevDfa &d) {
   return d.clsOff != 0 && d.deadAbsorbing &&
          d.clsBytes <= (d.clsIndexForm ? kStreamBigLds : kStreamTabBytes + 1024);
 }
 
+#if REDGPU_TU_GENERIC
 bool fastPathEligible(const DevDfa &d) {
   return d.tableKind == REDGPU_TAB_LDS_FUSED_U8 && d.deadAbsorbing &&
          size_t(d.tableBytes) + size_t(d.nStates) * 4 <= 150 * 1024;
 }
+#endif
 
+#if REDGPU_TU_STREAM
+// StatefulMatcher chunks the streaming kernels can take (k_stream<advance...>); *handled says so
+hipError_t launchAdvanceStream(const DevDfa &d, const Batch &b, uint32_t *state,
+                               const LaunchCfg &cfg, hipStream_t stream, const char **kernelName,
+                               bool *handled) {
+  *handled = false;
+  // chunks that are whole 64-byte blocks at a fixed stride: the streaming kernel
+  if (!cfg.forceGeneric && fastPathEligible(d) && !b.offsets && b.stride >= 64 &&
+      b.stride % 64 == 0 && b.stride < (1ull << 31) &&
+      (reinterpret_cast<uintptr_t>(b.data) % 16) == 0 && d.tableBytes <= kStreamTabBytes &&
+      d.nStates <= 256) {
+    *kernelName = "k_stream<advance>";
+    Batch sb = b;
+    sb.state = state;
+    sb.start = nullptr;
+    sb.end = nullptr;
+    *handled = true;
+    return launchStreamT<kSmAdvance>(d, sb, cfg, stream);
+  }
+  if (!cfg.forceGeneric && clsStreamEligible(d) && !b.offsets && b.stride >= 64 &&
+      b.stride % 64 == 0 && b.stride < (1ull << 31) &&
+      (reinterpret_cast<uintptr_t>(b.data) % 16) == 0) {
+    *kernelName = "k_stream<advance,cls>";
+    Batch sb = b;
+    sb.state = state;
+    sb.start = nullptr;
+    sb.end = nullptr;
+    *handled = true;
+    return d.clsIndexForm ? launchStreamHot<kSmAdvance, kTabClsBig>(d, sb, cfg, stream)
+                          : launchStreamHot<kSmAdvance, kTabCls>(d, sb, cfg, stream);
+  }
+  if (!cfg.forceGeneric && hotStreamEligible(d) && !b.offsets && b.stride >= 64 &&
+      b.stride % 64 == 0 && b.stride < (1ull << 31) &&
+      (reinterpret_cast<uintptr_t>(b.data) % 16) == 0) {
+    *kernelName = "k_stream<advance,hot>";
+    Batch sb = b;
+    sb.state = state;
+    sb.start = nullptr;
+    sb.end = nullptr;
+    *handled = true;
+    return launchStreamHot<kSmAdvance>(d, sb, cfg, stream);
+  }
+  return hipSuccess;
+}
+#endif  // REDGPU_TU_STREAM
+
+#if REDGPU_TU_STREAM
+// The fixed-stride family of launchBatch: speculative chunks, k_stream (fused / hot / class
+// table), k_fixed.  *handled = false: not this family's batch.
+hipError_t launchFixedFamily(const DevDfa &d, const Batch &b, int verb, int style, int doLeader,
+                             const LaunchCfg &cfg, hipStream_t stream, const char **kernelName,
+                             bool *handled) {
+  *handled = true;
+  const bool lead = doLeader && d.leaderLen > 0;
+  const bool dying = d.earlyDeath && !cfg.forceStream;
+  // Fixed-stride hot path: check / match, whole 16-byte multiples, 16-byte aligned base.
+  // check<.., true> consumes the leader and starts in the post-leader state at byte
+  // leaderLen (Matcher.h:370-375); match only peeks it (Matcher.h:424-435).
+  const bool fixedOk = !cfg.forceGeneric && !dying && fastPathEligible(d) && !b.offsets &&
+                       (verb == kCheck || verb == kMatch) && b.stride >= 16 &&
+                       b.stride % 16 == 0 && b.stride < (1ull << 31) &&
+                       (reinterpret_cast<uintptr_t>(b.data) % 16) == 0 &&
+                       !(lead && verb == kCheck);
+  // Streaming kernel: styles Last / Full on lines that are whole 64-byte blocks.
+  const bool streamOk = fixedOk && (style == kStyLast || style == kStyFull) &&
+                        b.stride % 64 == 0 && d.tableBytes <= kStreamTabBytes && d.nStates <= 256;
+  // The same streaming walk for DFAs too big for LDS: hot rows as a one-byte-indexed table,
+  // cold excursions re-walked per 64-byte half-block (k_stream.h, HOT).
+  const bool hotStreamOk = !cfg.forceGeneric && !dying && hotStreamEligible(d) && !b.offsets &&
+                           (verb == kCheck || verb == kMatch) &&
+                           (style == kStyLast || style == kStyFull) && b.stride >= 64 &&
+                           b.stride % 64 == 0 && b.stride < (1ull << 31) &&
+                           (reinterpret_cast<uintptr_t>(b.data) % 16) == 0 &&
+                           !(lead && verb == kCheck);
+  // ... and for mid-size DFAs whose class table fits 64 KB of LDS (two lookups per byte)
+  const bool clsStreamOk = !cfg.forceGeneric && !dying && clsStreamEligible(d) && !b.offsets &&
+                           (verb == kCheck || verb == kMatch) &&
+                           (style == kStyLast || style == kStyFull) && b.stride >= 64 &&
+                           b.stride % 64 == 0 && b.stride < (1ull << 31) &&
+                           (reinterpret_cast<uintptr_t>(b.data) % 16) == 0 &&
+                           !(lead && verb == kCheck);
+  // Few long lines over a DFA that forgets its past: chunks of every line walked at once from
+  // the initial state as a guess, wrong guesses re-walked (k_chunk.h)
+  if ((streamOk || hotStreamOk || clsStreamOk) && !cfg.noChunking &&
+      (d.forgetful || cfg.forceChunking) &&
+      (fewLines(b, cfg) || cfg.forceChunking)) {
+    const uint32_t m = chunksPerLine(b, cfg);
+    if (m) {
+      Batch sb = b;
+      if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
+      *kernelName = d.tableKind == REDGPU_TAB_HOT_ROWS ? "k_stream<chunk,hot>+k_chunk"
+                    : d.tableKind == REDGPU_TAB_LDS_FUSED_U8 ? "k_stream<chunk>+k_chunk"
+                                                             : "k_stream<chunk,cls>+k_chunk";
+      hipError_t e = launchChunked(d, sb, m, style, cfg, stream);
+      if (e != hipSuccess) return e;
+      if (lead) {
+        hipLaunchKernelGGL(k_leader_filter, dim3(uint32_t(cfg.numCUs) * 8), dim3(256), 0, stream,
+                           d, b);
+        return hipGetLastError();
+      }
+      return hipSuccess;
+    }
+  }
+  if (streamOk) {
+    hipError_t e;
+    Batch sb = b;
+    if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
+    if (stream4Eligible(d, sb, cfg)) {
+      const int mode = style == kStyLast ? (sb.start ? kSmLastStartEnd : kSmLastEnd)
+                                         : (sb.start ? kSmFullStart : kSmFull);
+      *kernelName = style == kStyLast ? (sb.start ? "k_stream4<last,start,end>" : "k_stream4<last,end>")
+                                      : (sb.start ? "k_stream4<full,start>" : "k_stream4<full>");
+      e = launchStream4(mode, d, sb, cfg, stream);
+    } else
+    if (style == kStyLast) {
+      if (sb.start) { *kernelName = "k_stream<last,start,end>"; e = launchStreamT<kSmLastStartEnd>(d, sb, cfg, stream); }
+      else { *kernelName = "k_stream<last,end>"; e = launchStreamT<kSmLastEnd>(d, sb, cfg, stream); }
+    } else {
+      if (sb.start) { *kernelName = "k_stream<full,start>"; e = launchStreamT<kSmFullStart>(d, sb, cfg, stream); }
+      else { *kernelName = "k_stream<full>"; e = launchStreamT<kSmFull>(d, sb, cfg, stream); }
+    }
+    if (e != hipSuccess) return e;
+    if (lead) {
+      hipLaunchKernelGGL(k_leader_filter, dim3(uint32_t(cfg.numCUs) * 8), dim3(256), 0, stream,
+                         d, b);
+      return hipGetLastError();
+    }
+    return hipSuccess;
+  }
+  if (hotStreamOk) {
+    hipError_t e;
+    Batch sb = b;
+    if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
+    if (style == kStyLast) {
+      if (sb.start) { *kernelName = "k_stream<last,start,end,hot>"; e = launchStreamHot<kSmLastStartEnd>(d, sb, cfg, stream); }
+      else { *kernelName = "k_stream<last,end,hot>"; e = launchStreamHot<kSmLastEnd>(d, sb, cfg, stream); }
+    } else {
+      if (sb.start) { *kernelName = "k_stream<full,start,hot>"; e = launchStreamHot<kSmFullStart>(d, sb, cfg, stream); }
+      else { *kernelName = "k_stream<full,hot>"; e = launchStreamHot<kSmFull>(d, sb, cfg, stream); }
+    }
+    if (e != hipSuccess) return e;
+    if (lead) {
+      hipLaunchKernelGGL(k_leader_filter, dim3(uint32_t(cfg.numCUs) * 8), dim3(256), 0, stream,
+                         d, b);
+      return hipGetLastError();
+    }
+    return hipSuccess;
+  }
+  if (clsStreamOk) {
+    hipError_t e;
+    Batch sb = b;
+    if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
+    if (style == kStyLast) {
+      if (sb.start) { *kernelName = "k_stream<last,start,end,cls>"; e = d.clsIndexForm ? launchStreamHot<kSmLastStartEnd, kTabClsBig>(d, sb, cfg, stream) : launchStreamHot<kSmLastStartEnd, kTabCls>(d, sb, cfg, stream); }
+      else { *kernelName = "k_stream<last,end,cls>"; e = d.clsIndexForm ? launchStreamHot<kSmLastEnd, kTabClsBig>(d, sb, cfg, stream) : launchStreamHot<kSmLastEnd, kTabCls>(d, sb, cfg, stream); }
+    } else {
+      if (sb.start) { *kernelName = "k_stream<full,start,cls>"; e = d.clsIndexForm ? launchStreamHot<kSmFullStart, kTabClsBig>(d, sb, cfg, stream) : launchStreamHot<kSmFullStart, kTabCls>(d, sb, cfg, stream); }
+      else { *kernelName = "k_stream<full,cls>"; e = d.clsIndexForm ? launchStreamHot<kSmFull, kTabClsBig>(d, sb, cfg, stream) : launchStreamHot<kSmFull, kTabCls>(d, sb, cfg, stream); }
+    }
+    if (e != hipSuccess) return e;
+    if (lead) {
+      hipLaunchKernelGGL(k_leader_filter, dim3(uint32_t(cfg.numCUs) * 8), dim3(256), 0, stream,
+                         d, b);
+      return hipGetLastError();
+    }
+    return hipSuccess;
+  }
+  if (fixedOk) {
+    hipError_t e;
+    if (verb == kCheck) {
+      *kernelName = "k_fixed<check>";
+      e = launchFixedS<false, false>(style, d, b, 0, d.init, cfg, stream);
+    } else if (b.start) {
+      *kernelName = "k_fixed<match,start>";
+      e = launchFixedS<true, true>(style, d, b, 0, d.init, cfg, stream);
+    } else {
+      *kernelName = "k_fixed<match>";
+      e = launchFixedS<true, false>(style, d, b, 0, d.init, cfg, stream);
+    }
+    if (e != hipSuccess) return e;
+    if (lead) {
+      hipLaunchKernelGGL(k_leader_filter, dim3(uint32_t(cfg.numCUs) * 8), dim3(256), 0, stream,
+                         d, b);
+      return hipGetLastError();
+    }
+    return hipSuccess;
+  }
+
+  *handled = false;
+  return hipSuccess;
+}
+#endif  // REDGPU_TU_STREAM
+
+#if REDGPU_TU_RAGGED
+// The ragged family of launchBatch: k_ragged over the fused, hot-row and class tables.
+hipError_t launchRaggedFamily(const DevDfa &d, const Batch &b, int verb, int style, int doLeader,
+                              const LaunchCfg &cfg, hipStream_t stream, const char **kernelName,
+                              bool *handled) {
+  *handled = true;
+  const bool lead = doLeader && d.leaderLen > 0;
+  const bool dying = d.earlyDeath && !cfg.forceStream;
+  // Ragged lines, fused-u8 table, styles Last / Full of check / match, no leader to honour:
+  // k_ragged walks every line; blocks that would reach past the end of the buffer come from a
+  // padded copy of its last bytes.
+  const bool raggedOk = !cfg.forceGeneric && !dying && fastPathEligible(d) && b.offsets &&
+                        b.n < (1ull << 32) &&
+                        (verb == kCheck || verb == kMatch) &&
+                        (style == kStyLast || style == kStyFull) && !lead &&
+                        d.tableBytes <= kStreamTabBytes && d.nStates <= 256;
+  if (raggedOk) {
+    hipError_t e;
+    Batch sb = b;
+    if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
+    if (style == kStyLast) {
+      if (sb.start) { *kernelName = "k_ragged<last,start,end>"; e = launchRaggedT<kSmLastStartEnd>(d, sb, cfg, stream); }
+      else { *kernelName = "k_ragged<last,end>"; e = launchRaggedT<kSmLastEnd>(d, sb, cfg, stream); }
+    } else {
+      if (sb.start) { *kernelName = "k_ragged<full,start>"; e = launchRaggedT<kSmFullStart>(d, sb, cfg, stream); }
+      else { *kernelName = "k_ragged<full>"; e = launchRaggedT<kSmFull>(d, sb, cfg, stream); }
+    }
+    return e;
+  }
+
+  // ... and the same for DFAs too big for LDS (hot rows, cold excursions re-walked per block).
+  // On ragged text matches sit at any offset, so with the create-time ranking some lane of a
+  // wave is in a cold excursion in nearly every block and the re-walks dominate (URI-V6 on
+  // geometric-length text with a URL every ~8 lines: 128 GB/s untuned, 556 GB/s after
+  // redgpu_dfa_tune) - still ahead of k_generic on the same lines (98 GB/s: its one-line-per-
+  // lane walk also pays the wave-max of the line lengths); without URLs 629 vs 107 GB/s.
+  const bool hotRaggedOk = !cfg.forceGeneric && !dying && hotStreamEligible(d) && b.offsets &&
+                           b.n < (1ull << 32) &&
+                           (verb == kCheck || verb == kMatch) &&
+                           (style == kStyLast || style == kStyFull) && !lead;
+  if (hotRaggedOk) {
+    Batch sb = b;
+    if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
+    if (style == kStyLast) {
+      if (sb.start) { *kernelName = "k_ragged<last,start,end,hot>"; return launchRaggedT<kSmLastStartEnd, kTabHot>(d, sb, cfg, stream); }
+      *kernelName = "k_ragged<last,end,hot>";
+      return launchRaggedT<kSmLastEnd, kTabHot>(d, sb, cfg, stream);
+    }
+    if (sb.start) { *kernelName = "k_ragged<full,start,hot>"; return launchRaggedT<kSmFullStart, kTabHot>(d, sb, cfg, stream); }
+    *kernelName = "k_ragged<full,hot>";
+    return launchRaggedT<kSmFull, kTabHot>(d, sb, cfg, stream);
+  }
+
+  // ... and for mid-size DFAs with a class table of at most 64 KB
+  const bool clsRaggedOk = !cfg.forceGeneric && !dying && clsStreamEligible(d) && b.offsets &&
+                           b.n < (1ull << 32) &&
+                           (verb == kCheck || verb == kMatch) &&
+                           (style == kStyLast || style == kStyFull) && !lead;
+  if (clsRaggedOk) {
+    Batch sb = b;
+    if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
+    if (style == kStyLast) {
+      if (sb.start) { *kernelName = "k_ragged<last,start,end,cls>"; return d.clsIndexForm ? launchRaggedT<kSmLastStartEnd, kTabClsBig>(d, sb, cfg, stream) : launchRaggedT<kSmLastStartEnd, kTabCls>(d, sb, cfg, stream); }
+      *kernelName = "k_ragged<last,end,cls>";
+      return d.clsIndexForm ? launchRaggedT<kSmLastEnd, kTabClsBig>(d, sb, cfg, stream) : launchRaggedT<kSmLastEnd, kTabCls>(d, sb, cfg, stream);
+    }
+    if (sb.start) { *kernelName = "k_ragged<full,start,cls>"; return d.clsIndexForm ? launchRaggedT<kSmFullStart, kTabClsBig>(d, sb, cfg, stream) : launchRaggedT<kSmFullStart, kTabCls>(d, sb, cfg, stream); }
+    *kernelName = "k_ragged<full,cls>";
+    return d.clsIndexForm ? launchRaggedT<kSmFull, kTabClsBig>(d, sb, cfg, stream) : launchRaggedT<kSmFull, kTabCls>(d, sb, cfg, stream);
+  }
+
+  *handled = false;
+  return hipSuccess;
+}
+#endif  // REDGPU_TU_RAGGED
+
+#if REDGPU_TU_GENERIC
 hipError_t launchCollect(const DevDfa &d, const Batch &b, uint64_t cap, uint64_t *counts,
                          const LaunchCfg &cfg, hipStream_t stream) {
   if (b.n == 0) return hipSuccess;
@@ -2356,39 +2639,9 @@ hipError_t launchAdvance(const DevDfa &d, const Batch &b, uint32_t *state, const
                          hipStream_t stream, const char **kernelName) {
   *kernelName = "k_advance";
   if (b.n == 0) return hipSuccess;
-  // chunks that are whole 64-byte blocks at a fixed stride: the streaming kernel
-  if (!cfg.forceGeneric && fastPathEligible(d) && !b.offsets && b.stride >= 64 &&
-      b.stride % 64 == 0 && b.stride < (1ull << 31) &&
-      (reinterpret_cast<uintptr_t>(b.data) % 16) == 0 && d.tableBytes <= kStreamTabBytes &&
-      d.nStates <= 256) {
-    *kernelName = "k_stream<advance>";
-    Batch sb = b;
-    sb.state = state;
-    sb.start = nullptr;
-    sb.end = nullptr;
-    return launchStreamT<kSmAdvance>(d, sb, cfg, stream);
-  }
-  if (!cfg.forceGeneric && clsStreamEligible(d) && !b.offsets && b.stride >= 64 &&
-      b.stride % 64 == 0 && b.stride < (1ull << 31) &&
-      (reinterpret_cast<uintptr_t>(b.data) % 16) == 0) {
-    *kernelName = "k_stream<advance,cls>";
-    Batch sb = b;
-    sb.state = state;
-    sb.start = nullptr;
-    sb.end = nullptr;
-    return d.clsIndexForm ? launchStreamHot<kSmAdvance, kTabClsBig>(d, sb, cfg, stream)
-                          : launchStreamHot<kSmAdvance, kTabCls>(d, sb, cfg, stream);
-  }
-  if (!cfg.forceGeneric && hotStreamEligible(d) && !b.offsets && b.stride >= 64 &&
-      b.stride % 64 == 0 && b.stride < (1ull << 31) &&
-      (reinterpret_cast<uintptr_t>(b.data) % 16) == 0) {
-    *kernelName = "k_stream<advance,hot>";
-    Batch sb = b;
-    sb.state = state;
-    sb.start = nullptr;
-    sb.end = nullptr;
-    return launchStreamHot<kSmAdvance>(d, sb, cfg, stream);
-  }
+  bool handled = false;
+  hipError_t se = launchAdvanceStream(d, b, state, cfg, stream, kernelName, &handled);
+  if (handled || se != hipSuccess) return se;
 #define AD_CALL(K) launchAdvanceK<K>(d, b, state, cfg, stream)
   REDGPU_KIND_SWITCH(AD_CALL)
 #undef AD_CALL
@@ -2405,7 +2658,6 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
   // with k_generic: the whole-line kernels below read and walk every byte, k_generic stops
   // where the reference's loop stops - measured on ERR 1.3x (64-byte lines) to 38x (4 KiB
   // lines) faster (scripts/bench_anchored.py).
-  const bool dying = d.earlyDeath && !cfg.forceStream;
   // match over an early-death DFA whose table lives in LDS: probe every line for a few bytes,
   // park the survivors, walk them densely (k_early)
   const bool earlyKind = d.tableKind == REDGPU_TAB_LDS_FUSED_U8 || d.tableKind == REDGPU_TAB_LDS_FUSED_U16 ||
@@ -2422,200 +2674,12 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
     }
   }
 
-  // Fixed-stride hot path: check / match, whole 16-byte multiples, 16-byte aligned base.
-  // check<.., true> consumes the leader and starts in the post-leader state at byte
-  // leaderLen (Matcher.h:370-375); match only peeks it (Matcher.h:424-435).
-  const bool fixedOk = !cfg.forceGeneric && !dying && fastPathEligible(d) && !b.offsets &&
-                       (verb == kCheck || verb == kMatch) && b.stride >= 16 &&
-                       b.stride % 16 == 0 && b.stride < (1ull << 31) &&
-                       (reinterpret_cast<uintptr_t>(b.data) % 16) == 0 &&
-                       !(lead && verb == kCheck);
-  // Streaming kernel: styles Last / Full on lines that are whole 64-byte blocks.
-  const bool streamOk = fixedOk && (style == kStyLast || style == kStyFull) &&
-                        b.stride % 64 == 0 && d.tableBytes <= kStreamTabBytes && d.nStates <= 256;
-  // The same streaming walk for DFAs too big for LDS: hot rows as a one-byte-indexed table,
-  // cold excursions re-walked per 64-byte half-block (k_stream.h, HOT).
-  const bool hotStreamOk = !cfg.forceGeneric && !dying && hotStreamEligible(d) && !b.offsets &&
-                           (verb == kCheck || verb == kMatch) &&
-                           (style == kStyLast || style == kStyFull) && b.stride >= 64 &&
-                           b.stride % 64 == 0 && b.stride < (1ull << 31) &&
-                           (reinterpret_cast<uintptr_t>(b.data) % 16) == 0 &&
-                           !(lead && verb == kCheck);
-  // ... and for mid-size DFAs whose class table fits 64 KB of LDS (two lookups per byte)
-  const bool clsStreamOk = !cfg.forceGeneric && !dying && clsStreamEligible(d) && !b.offsets &&
-                           (verb == kCheck || verb == kMatch) &&
-                           (style == kStyLast || style == kStyFull) && b.stride >= 64 &&
-                           b.stride % 64 == 0 && b.stride < (1ull << 31) &&
-                           (reinterpret_cast<uintptr_t>(b.data) % 16) == 0 &&
-                           !(lead && verb == kCheck);
-  // Few long lines over a DFA that forgets its past: chunks of every line walked at once from
-  // the initial state as a guess, wrong guesses re-walked (k_chunk.h)
-  if ((streamOk || hotStreamOk || clsStreamOk) && !cfg.noChunking &&
-      (d.forgetful || cfg.forceChunking) &&
-      (fewLines(b, cfg) || cfg.forceChunking)) {
-    const uint32_t m = chunksPerLine(b, cfg);
-    if (m) {
-      Batch sb = b;
-      if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
-      *kernelName = d.tableKind == REDGPU_TAB_HOT_ROWS ? "k_stream<chunk,hot>+k_chunk"
-                    : d.tableKind == REDGPU_TAB_LDS_FUSED_U8 ? "k_stream<chunk>+k_chunk"
-                                                             : "k_stream<chunk,cls>+k_chunk";
-      hipError_t e = launchChunked(d, sb, m, style, cfg, stream);
-      if (e != hipSuccess) return e;
-      if (lead) {
-        hipLaunchKernelGGL(k_leader_filter, dim3(uint32_t(cfg.numCUs) * 8), dim3(256), 0, stream,
-                           d, b);
-        return hipGetLastError();
-      }
-      return hipSuccess;
-    }
-  }
-  if (streamOk) {
-    hipError_t e;
-    Batch sb = b;
-    if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
-    if (stream4Eligible(d, sb, cfg)) {
-      const int mode = style == kStyLast ? (sb.start ? kSmLastStartEnd : kSmLastEnd)
-                                         : (sb.start ? kSmFullStart : kSmFull);
-      *kernelName = style == kStyLast ? (sb.start ? "k_stream4<last,start,end>" : "k_stream4<last,end>")
-                                      : (sb.start ? "k_stream4<full,start>" : "k_stream4<full>");
-      e = launchStream4(mode, d, sb, cfg, stream);
-    } else
-    if (style == kStyLast) {
-      if (sb.start) { *kernelName = "k_stream<last,start,end>"; e = launchStreamT<kSmLastStartEnd>(d, sb, cfg, stream); }
-      else { *kernelName = "k_stream<last,end>"; e = launchStreamT<kSmLastEnd>(d, sb, cfg, stream); }
-    } else {
-      if (sb.start) { *kernelName = "k_stream<full,start>"; e = launchStreamT<kSmFullStart>(d, sb, cfg, stream); }
-      else { *kernelName = "k_stream<full>"; e = launchStreamT<kSmFull>(d, sb, cfg, stream); }
-    }
-    if (e != hipSuccess) return e;
-    if (lead) {
-      hipLaunchKernelGGL(k_leader_filter, dim3(uint32_t(cfg.numCUs) * 8), dim3(256), 0, stream,
-                         d, b);
-      return hipGetLastError();
-    }
-    return hipSuccess;
-  }
-  if (hotStreamOk) {
-    hipError_t e;
-    Batch sb = b;
-    if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
-    if (style == kStyLast) {
-      if (sb.start) { *kernelName = "k_stream<last,start,end,hot>"; e = launchStreamHot<kSmLastStartEnd>(d, sb, cfg, stream); }
-      else { *kernelName = "k_stream<last,end,hot>"; e = launchStreamHot<kSmLastEnd>(d, sb, cfg, stream); }
-    } else {
-      if (sb.start) { *kernelName = "k_stream<full,start,hot>"; e = launchStreamHot<kSmFullStart>(d, sb, cfg, stream); }
-      else { *kernelName = "k_stream<full,hot>"; e = launchStreamHot<kSmFull>(d, sb, cfg, stream); }
-    }
-    if (e != hipSuccess) return e;
-    if (lead) {
-      hipLaunchKernelGGL(k_leader_filter, dim3(uint32_t(cfg.numCUs) * 8), dim3(256), 0, stream,
-                         d, b);
-      return hipGetLastError();
-    }
-    return hipSuccess;
-  }
-  if (clsStreamOk) {
-    hipError_t e;
-    Batch sb = b;
-    if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
-    if (style == kStyLast) {
-      if (sb.start) { *kernelName = "k_stream<last,start,end,cls>"; e = d.clsIndexForm ? launchStreamHot<kSmLastStartEnd, kTabClsBig>(d, sb, cfg, stream) : launchStreamHot<kSmLastStartEnd, kTabCls>(d, sb, cfg, stream); }
-      else { *kernelName = "k_stream<last,end,cls>"; e = d.clsIndexForm ? launchStreamHot<kSmLastEnd, kTabClsBig>(d, sb, cfg, stream) : launchStreamHot<kSmLastEnd, kTabCls>(d, sb, cfg, stream); }
-    } else {
-      if (sb.start) { *kernelName = "k_stream<full,start,cls>"; e = d.clsIndexForm ? launchStreamHot<kSmFullStart, kTabClsBig>(d, sb, cfg, stream) : launchStreamHot<kSmFullStart, kTabCls>(d, sb, cfg, stream); }
-      else { *kernelName = "k_stream<full,cls>"; e = d.clsIndexForm ? launchStreamHot<kSmFull, kTabClsBig>(d, sb, cfg, stream) : launchStreamHot<kSmFull, kTabCls>(d, sb, cfg, stream); }
-    }
-    if (e != hipSuccess) return e;
-    if (lead) {
-      hipLaunchKernelGGL(k_leader_filter, dim3(uint32_t(cfg.numCUs) * 8), dim3(256), 0, stream,
-                         d, b);
-      return hipGetLastError();
-    }
-    return hipSuccess;
-  }
-  if (fixedOk) {
-    hipError_t e;
-    if (verb == kCheck) {
-      *kernelName = "k_fixed<check>";
-      e = launchFixedS<false, false>(style, d, b, 0, d.init, cfg, stream);
-    } else if (b.start) {
-      *kernelName = "k_fixed<match,start>";
-      e = launchFixedS<true, true>(style, d, b, 0, d.init, cfg, stream);
-    } else {
-      *kernelName = "k_fixed<match>";
-      e = launchFixedS<true, false>(style, d, b, 0, d.init, cfg, stream);
-    }
-    if (e != hipSuccess) return e;
-    if (lead) {
-      hipLaunchKernelGGL(k_leader_filter, dim3(uint32_t(cfg.numCUs) * 8), dim3(256), 0, stream,
-                         d, b);
-      return hipGetLastError();
-    }
-    return hipSuccess;
-  }
-
-  // Ragged lines, fused-u8 table, styles Last / Full of check / match, no leader to honour:
-  // k_ragged walks every line; blocks that would reach past the end of the buffer come from a
-  // padded copy of its last bytes.
-  const bool raggedOk = !cfg.forceGeneric && !dying && fastPathEligible(d) && b.offsets &&
-                        b.n < (1ull << 32) &&
-                        (verb == kCheck || verb == kMatch) &&
-                        (style == kStyLast || style == kStyFull) && !lead &&
-                        d.tableBytes <= kStreamTabBytes && d.nStates <= 256;
-  if (raggedOk) {
-    hipError_t e;
-    Batch sb = b;
-    if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
-    if (style == kStyLast) {
-      if (sb.start) { *kernelName = "k_ragged<last,start,end>"; e = launchRaggedT<kSmLastStartEnd>(d, sb, cfg, stream); }
-      else { *kernelName = "k_ragged<last,end>"; e = launchRaggedT<kSmLastEnd>(d, sb, cfg, stream); }
-    } else {
-      if (sb.start) { *kernelName = "k_ragged<full,start>"; e = launchRaggedT<kSmFullStart>(d, sb, cfg, stream); }
-      else { *kernelName = "k_ragged<full>"; e = launchRaggedT<kSmFull>(d, sb, cfg, stream); }
-    }
-    return e;
-  }
-
-  // ... and the same for DFAs too big for LDS (hot rows, cold excursions re-walked per block).
-  // On ragged text matches sit at any offset, so with the create-time ranking some lane of a
-  // wave is in a cold excursion in nearly every block and the re-walks dominate (URI-V6 on
-  // geometric-length text with a URL every ~8 lines: 128 GB/s untuned, 556 GB/s after
-  // redgpu_dfa_tune) - still ahead of k_generic on the same lines (98 GB/s: its one-line-per-
-  // lane walk also pays the wave-max of the line lengths); without URLs 629 vs 107 GB/s.
-  const bool hotRaggedOk = !cfg.forceGeneric && !dying && hotStreamEligible(d) && b.offsets &&
-                           b.n < (1ull << 32) &&
-                           (verb == kCheck || verb == kMatch) &&
-                           (style == kStyLast || style == kStyFull) && !lead;
-  if (hotRaggedOk) {
-    Batch sb = b;
-    if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
-    if (style == kStyLast) {
-      if (sb.start) { *kernelName = "k_ragged<last,start,end,hot>"; return launchRaggedT<kSmLastStartEnd, kTabHot>(d, sb, cfg, stream); }
-      *kernelName = "k_ragged<last,end,hot>";
-      return launchRaggedT<kSmLastEnd, kTabHot>(d, sb, cfg, stream);
-    }
-    if (sb.start) { *kernelName = "k_ragged<full,start,hot>"; return launchRaggedT<kSmFullStart, kTabHot>(d, sb, cfg, stream); }
-    *kernelName = "k_ragged<full,hot>";
-    return launchRaggedT<kSmFull, kTabHot>(d, sb, cfg, stream);
-  }
-
-  // ... and for mid-size DFAs with a class table of at most 64 KB
-  const bool clsRaggedOk = !cfg.forceGeneric && !dying && clsStreamEligible(d) && b.offsets &&
-                           b.n < (1ull << 32) &&
-                           (verb == kCheck || verb == kMatch) &&
-                           (style == kStyLast || style == kStyFull) && !lead;
-  if (clsRaggedOk) {
-    Batch sb = b;
-    if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
-    if (style == kStyLast) {
-      if (sb.start) { *kernelName = "k_ragged<last,start,end,cls>"; return d.clsIndexForm ? launchRaggedT<kSmLastStartEnd, kTabClsBig>(d, sb, cfg, stream) : launchRaggedT<kSmLastStartEnd, kTabCls>(d, sb, cfg, stream); }
-      *kernelName = "k_ragged<last,end,cls>";
-      return d.clsIndexForm ? launchRaggedT<kSmLastEnd, kTabClsBig>(d, sb, cfg, stream) : launchRaggedT<kSmLastEnd, kTabCls>(d, sb, cfg, stream);
-    }
-    if (sb.start) { *kernelName = "k_ragged<full,start,cls>"; return d.clsIndexForm ? launchRaggedT<kSmFullStart, kTabClsBig>(d, sb, cfg, stream) : launchRaggedT<kSmFullStart, kTabCls>(d, sb, cfg, stream); }
-    *kernelName = "k_ragged<full,cls>";
-    return d.clsIndexForm ? launchRaggedT<kSmFull, kTabClsBig>(d, sb, cfg, stream) : launchRaggedT<kSmFull, kTabCls>(d, sb, cfg, stream);
+  {
+    bool handled = false;
+    hipError_t fe = launchFixedFamily(d, b, verb, style, doLeader, cfg, stream, kernelName, &handled);
+    if (handled || fe != hipSuccess) return fe;
+    fe = launchRaggedFamily(d, b, verb, style, doLeader, cfg, stream, kernelName, &handled);
+    if (handled || fe != hipSuccess) return fe;
   }
 
   {
@@ -2641,5 +2705,7 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
     return launchGeneric<REDGPU_TAB_GLOBAL_U32>(d, b, verb, style, lead, cfg, stream);
   }
 }
+
+#endif  // REDGPU_TU_GENERIC
 
 } // namespace redgpu

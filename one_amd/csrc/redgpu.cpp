@@ -103,7 +103,16 @@ enum StageSlot : int {
   kSlAux3 = 12,
 };
 
-constexpr uint64_t kHostChunkBytes = 32ull << 20;
+// chunk size of the host-buffer pipeline (REDGPU_HOST_CHUNK_MB overrides: tuning)
+static uint64_t hostChunkBytes() {
+  static const uint64_t v = [] {
+    const char *e = getenv("REDGPU_HOST_CHUNK_MB");
+    const long mb = e ? atol(e) : 0;
+    return uint64_t(mb >= 1 && mb <= 1024 ? mb : 32) << 20;
+  }();
+  return v;
+}
+#define kHostChunkBytes hostChunkBytes()
 
 // offsets of a chunk that does not start at byte 0, rebased to the chunk's own buffer: the
 // kernels may read data[0, offsets[n]) anywhere (lanes without a line re-read block 0), so a

@@ -165,6 +165,45 @@ inline std::vector<Outcome> matchBatch(const Executable &exec, const std::vector
   return out;
 }
 
+// ---- several GPUs of one node: one image per device, contiguous shards, results in the caller's
+// arrays - the device form of tools/thr_red.cpp:84-91 (N workers over one shared Red).  devices
+// may name a device more than once (the shards then share it). ----------------------------------
+class Group {
+public:
+  Group(std::string_view serialized, const std::vector<int32_t> &devices) : g_(nullptr) {
+    if (serialized.empty()) throw RedExceptApi("serialized dfa string_view is empty");
+    throwOnError(redgpu_group_create(serialized.data(), serialized.size(), nullptr, devices.data(),
+                                     uint32_t(devices.size()), &g_));
+  }
+  ~Group() { redgpu_group_destroy(g_); }
+  Group(const Group &) = delete;
+  Group &operator=(const Group &) = delete;
+  uint32_t size() const { return redgpu_group_size(g_); }
+  const redgpu_dfa *member(uint32_t i) const { return redgpu_group_member(g_, i); }
+  // shard g = lines [cuts[g], cuts[g + 1]): equal lines, or equal bytes when offsets are given
+  std::vector<uint64_t> plan(const uint64_t *offsets, uint64_t stride, uint64_t n) const {
+    std::vector<uint64_t> cuts(size() + 1);
+    throwOnError(redgpu_group_plan(g_, offsets, stride, n, cuts.data()));
+    return cuts;
+  }
+  template <Style style, bool doLeader>
+  void matchBatch(const Byte *data, const uint64_t *offsets, uint64_t stride, uint64_t n,
+                  Result *result, uint64_t *start, uint64_t *end) const {
+    throwOnError(redgpu_group_batch(g_, REDGPU_VERB_MATCH, style, doLeader, data, offsets, stride, n,
+                                    result, start, end));
+  }
+  template <Style style, bool doLeader>
+  void checkBatch(const Byte *data, const uint64_t *offsets, uint64_t stride, uint64_t n,
+                  Result *result) const {
+    throwOnError(redgpu_group_batch(g_, REDGPU_VERB_CHECK, style, doLeader, data, offsets, stride, n,
+                                    result, nullptr, nullptr));
+  }
+  redgpu_group *handle() const { return g_; }
+
+private:
+  redgpu_group *g_;
+};
+
 // ---- single-input forms with the reference's signatures (a batch of one on the GPU) ---------
 namespace detail {
 inline Result one(int (*fn)(const redgpu_dfa *, int, int, const uint8_t *, const uint64_t *,

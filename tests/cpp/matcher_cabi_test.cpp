@@ -5,6 +5,8 @@
 #include <fstream>
 #include <iterator>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "redgpu.hpp"
 
@@ -150,6 +152,52 @@ int main(int argc, char **argv) {
     EXPECT_EQ(true, threw);
     Executable moved(std::move(rex));  // test/executable.cpp:55-63 move semantics
     EXPECT_EQ(1, check(moved, "error", styFull));
+  }
+  // tools/thr_red.cpp:84-91: N std::threads over ONE shared read-only matcher - here over one
+  // redgpu_dfa (host-buffer batches, staged per thread), then the same lines through a Group of
+  // three shards on device 0; every worker's answers equal the single-threaded ones
+  {
+    Executable rex(slurp(dir + "/uri.reda"));
+    const std::string url = "see https://ab-c.example.com:8080/p/x.y?q=1#frag ok ";
+    std::string flat;
+    std::vector<uint64_t> off{0};
+    for (int i = 0; i < 6000; ++i) {
+      flat += (i % 3 == 0) ? url : std::string(size_t(5 + i % 40), char('a' + i % 7));
+      off.push_back(flat.size());
+    }
+    const uint64_t n = off.size() - 1;
+    std::vector<Result> r0(n);
+    std::vector<uint64_t> s0(n), e0(n);
+    matchBatch<styLast, false>(rex, reinterpret_cast<const Byte *>(flat.data()), off.data(), 0, n,
+                               r0.data(), s0.data(), e0.data());
+    int hits = 0;
+    for (uint64_t i = 0; i < n; ++i) hits += r0[i] > 0;
+    EXPECT_EQ(2000, hits);
+    std::vector<int> bad(8, 0);
+    std::vector<std::thread> workers;
+    for (int t = 0; t < 8; ++t)
+      workers.emplace_back([&, t] {
+        for (int rep = 0; rep < 5; ++rep) {
+          std::vector<Result> r(n);
+          std::vector<uint64_t> s(n), e(n);
+          matchBatch<styLast, false>(rex, reinterpret_cast<const Byte *>(flat.data()), off.data(), 0,
+                                     n, r.data(), s.data(), e.data());
+          if (r != r0 || s != s0 || e != e0) ++bad[t];
+        }
+        redgpu_thread_release();
+      });
+    for (auto &w : workers) w.join();
+    for (int t = 0; t < 8; ++t) EXPECT_EQ(0, bad[t]);
+    Group grp(rex.serialized(), {0, 0, 0});
+    EXPECT_EQ(uint32_t(3), grp.size());
+    const std::vector<uint64_t> cuts = grp.plan(off.data(), 0, n);
+    EXPECT_EQ(uint64_t(0), cuts[0]);
+    EXPECT_EQ(n, cuts[3]);
+    std::vector<Result> rg(n);
+    std::vector<uint64_t> sg(n), eg(n);
+    grp.matchBatch<styLast, false>(reinterpret_cast<const Byte *>(flat.data()), off.data(), 0, n,
+                                   rg.data(), sg.data(), eg.data());
+    EXPECT_EQ(true, rg == r0 && sg == s0 && eg == e0);
   }
   std::printf(failures ? "%d FAILURES\n" : "all C++ mirror checks passed\n", failures);
   return failures ? 1 : 0;

@@ -1103,7 +1103,7 @@ def test_cpp_mirror_through_cabi(tmp_path):
     exe = str(tmp_path / "matcher_cabi_test")
     subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
                     os.path.join(root, "tests", "cpp", "matcher_cabi_test.cpp"), "-o", exe,
-                    "-L", os.path.join(root, "one_amd"), "-lredgpu",
+                    "-L", os.path.join(root, "one_amd"), "-lredgpu", "-lpthread",
                     "-Wl,-rpath," + os.path.join(root, "one_amd")], check=True)
     out = subprocess.run([exe, os.path.join(root, "tests", "golden", "dfas")],
                          capture_output=True, text=True)

@@ -538,6 +538,62 @@ struct AnyWalk : MatchWalk {
   }
 };
 
+// include/Matcher.h:363-410 without the leader (doLeader false, or a DFA that has none): the
+// state checkCore's loop carries from byte to byte, resumable like MatchWalk, for k_early.
+// checkLane below stays the general form (it also consumes a leader).
+struct CheckWalk {
+  uint32_t s;
+  int32_t result, prev;
+  bool returned;
+  int32_t retval;
+  __device__ __forceinline__ void begin(const LaneCtx &c) {
+    s = c.init;
+    result = c.resultOf(s);
+    prev = 0;
+    returned = false;
+    retval = 0;
+  }
+  template <class T>
+  __device__ __forceinline__ bool step(const T &tab, const LaneCtx &c, int style, uint32_t byte,
+                                       uint64_t) {
+    s = tab.next(s, byte);
+    if (s >= c.firstAccept) {
+      result = c.res[s];
+      if (style == kStyInstant) { returned = true; retval = result; return false; }
+      if (style == kStyFirst) {
+        if (prev && result != prev) { returned = true; retval = prev; return false; }
+        prev = result;
+      }
+      if (style == kStyTangent || style == kStyLast) prev = result;
+    } else {
+      result = 0;
+      if ((style == kStyFirst || style == kStyTangent) && prev > 0) {
+        returned = true; retval = prev; return false;
+      }
+      if (s < c.nPureDead) return false;
+    }
+    return true;
+  }
+  __device__ __forceinline__ int32_t finish(const LaneCtx &, int style, uint64_t &startOut,
+                                            uint64_t &endOut) {
+    startOut = 0;
+    endOut = 0;
+    if (returned) return retval;
+    if (style == kStyLast && result == 0 && prev > 0) return prev;
+    return result;
+  }
+  __device__ __forceinline__ uint4 pack(uint32_t line) const {
+    return make_uint4(line, s, uint32_t(prev), uint32_t(result));
+  }
+  __device__ __forceinline__ void unpack(const uint4 &e) {
+    s = e.y;
+    prev = int32_t(e.z);
+    result = int32_t(e.w);
+    returned = false;
+    retval = 0;
+  }
+};
+
 template <class T>
 __device__ int32_t matchLane(const T &tab, const LaneCtx &c, const uint8_t *p, uint64_t n,
                              int style, bool lead, uint64_t &startOut, uint64_t &endOut) {
@@ -2062,8 +2118,9 @@ hipError_t launchEarlyV(const DevDfa &d, const Batch &b, int style, int lead, co
 }
 
 template <int KIND>
-hipError_t launchEarlyK(const DevDfa &d, const Batch &b, int style, int lead, const LaunchCfg &cfg,
-                        hipStream_t stream) {
+hipError_t launchEarlyK(const DevDfa &d, const Batch &b, int verb, int style, int lead,
+                        const LaunchCfg &cfg, hipStream_t stream) {
+  if (verb == kCheck) return launchEarlyV<KIND, CheckWalk, 2, 4>(d, b, style, 0, cfg, stream);
   if (style != kStyLast) return launchEarlyV<KIND, AnyWalk, 2, 4>(d, b, style, lead, cfg, stream);
   return launchEarlyV<KIND, LastWalk, 2, 6>(d, b, style, lead, cfg, stream);
 }
@@ -2662,15 +2719,17 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
   // park the survivors, walk them densely (k_early)
   const bool earlyKind = d.tableKind == REDGPU_TAB_LDS_FUSED_U8 || d.tableKind == REDGPU_TAB_LDS_FUSED_U16 ||
                          d.tableKind == REDGPU_TAB_LDS_CLASS_U16 || d.tableKind == REDGPU_TAB_LDS_SPARSE;
-  if (verb == kMatch && earlyKind && !cfg.forceGeneric && b.n < (1ull << 32) && d.nStates <= 65535 &&
+  // (check with a leader consumes it and starts in the post-leader state: k_generic's checkLane)
+  if ((verb == kMatch || (verb == kCheck && !lead)) && earlyKind && !cfg.forceGeneric &&
+      b.n < (1ull << 32) && d.nStates <= 65535 &&
       size_t(d.tableBytes) + 512 + 16384 + 1024 <= size_t(160) * 1024 &&
       (cfg.forceEarly || (d.earlyDeath && !cfg.forceStream && b.n >= 16384))) {
-    *kernelName = "k_early<match>";
+    *kernelName = verb == kMatch ? "k_early<match>" : "k_early<check>";
     switch (d.tableKind) {
-    case REDGPU_TAB_LDS_FUSED_U8: return launchEarlyK<REDGPU_TAB_LDS_FUSED_U8>(d, b, style, lead, cfg, stream);
-    case REDGPU_TAB_LDS_FUSED_U16: return launchEarlyK<REDGPU_TAB_LDS_FUSED_U16>(d, b, style, lead, cfg, stream);
-    case REDGPU_TAB_LDS_CLASS_U16: return launchEarlyK<REDGPU_TAB_LDS_CLASS_U16>(d, b, style, lead, cfg, stream);
-    default: return launchEarlyK<REDGPU_TAB_LDS_SPARSE>(d, b, style, lead, cfg, stream);
+    case REDGPU_TAB_LDS_FUSED_U8: return launchEarlyK<REDGPU_TAB_LDS_FUSED_U8>(d, b, verb, style, lead, cfg, stream);
+    case REDGPU_TAB_LDS_FUSED_U16: return launchEarlyK<REDGPU_TAB_LDS_FUSED_U16>(d, b, verb, style, lead, cfg, stream);
+    case REDGPU_TAB_LDS_CLASS_U16: return launchEarlyK<REDGPU_TAB_LDS_CLASS_U16>(d, b, verb, style, lead, cfg, stream);
+    default: return launchEarlyK<REDGPU_TAB_LDS_SPARSE>(d, b, verb, style, lead, cfg, stream);
     }
   }
 

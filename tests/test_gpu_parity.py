@@ -191,6 +191,11 @@ def test_probe_and_drain_kernel_vs_oracle(name):
             assert one_amd.last_kernel() == "k_early<match>"
             assert np.array_equal(r, er), (name, si, lead)
             assert np.array_equal(s, es) and np.array_equal(e, ee), (name, si, lead)
+            cr = one_amd.check_batch(exe, data, si, lead, offsets=offsets)
+            want = "k_early<check>" if not (lead and exe.info["leader_len"]) else "k_generic"
+            assert one_amd.last_kernel() == want, one_amd.last_kernel()
+            assert np.array_equal(cr, cpu.batch("check", si, lead, data, offsets=offsets,
+                                                threads=4)[0]), (name, "check", si, lead)
     for stride, m in ((64, 9000), (8, 5000), (24, 3001), (256, 2500)):
         fixed = _fixed_inputs(name, m, stride, seed=stride) if name in (
             "syn256", "uri", "err", "num3", "newyork") else W.fixed_lines(m, stride, stride)

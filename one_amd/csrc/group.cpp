@@ -9,7 +9,9 @@
 // Built with hipcc as HIP (the two pack / unpack kernels live here).
 #include <dlfcn.h>
 
+#include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <thread>
 
@@ -153,8 +155,45 @@ hipError_t grow(void **p, size_t *cap, size_t bytes) {
 
 }  // namespace
 
+// One long-lived host thread per shard > 0 of the HOST form (the caller's thread takes shard 0):
+// a worker keeps its per-thread staging (host_stage.h) from call to call, as one of thr_red's
+// workers would - threads made per call would allocate and free it every time.
+struct Worker {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool pending = false, stop = false, done = true;
+  void loop() {
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      cv.wait(lk, [&] { return pending || stop; });
+      if (stop) return;
+      pending = false;
+      lk.unlock();
+      job();
+      lk.lock();
+      done = true;
+      cv.notify_all();
+    }
+  }
+  void post(std::function<void()> f) {
+    std::lock_guard<std::mutex> lk(m);
+    job = std::move(f);
+    pending = true;
+    done = false;
+    cv.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [&] { return done; });
+  }
+};
+
 struct redgpu_group {
   std::vector<Member> m;
+  std::vector<std::unique_ptr<Worker>> workers;  // [k - 1] serves shard k of the host form
+  std::mutex hostMu;        // the host form: one call at a time per group
   std::mutex mu;            // the device form: one call at a time
   uint8_t *rootRec = nullptr;
   size_t rootRecCap = 0;
@@ -207,12 +246,25 @@ int redgpu_group_create(const void *reda, size_t len, const redgpu_opts *opts,
         if (hipDeviceEnablePeerAccess(devices[0], 0) != hipSuccess) (void)hipGetLastError();
     }
   }
+  for (uint32_t i = 1; i < n_devices; ++i) {
+    g->workers.emplace_back(new Worker());
+    Worker *w = g->workers.back().get();
+    w->th = std::thread([w] { w->loop(); });
+  }
   *out = g.release();
   return REDGPU_OK;
 }
 
 void redgpu_group_destroy(redgpu_group *g) {
   if (!g) return;
+  for (auto &w : g->workers) {
+    {
+      std::lock_guard<std::mutex> lk(w->m);
+      w->stop = true;
+      w->cv.notify_all();
+    }
+    if (w->th.joinable()) w->th.join();  // its staging goes with the thread
+  }
   for (Member &mb : g->m) {
     if (mb.device >= 0) {
       DeviceScope scope(mb.device);
@@ -306,10 +358,12 @@ int redgpu_group_batch(const redgpu_group *g, int verb, int style, int do_leader
     if (rc != REDGPU_OK) msgs[k] = redgpu_last_error();
   };
   // one host thread per device, as thr_red.cpp runs one per core; the caller's thread takes shard 0
-  std::vector<std::thread> threads;
-  for (size_t k = 1; k < G; ++k) threads.emplace_back(work, k);
-  work(0);
-  for (auto &t : threads) t.join();
+  {
+    std::lock_guard<std::mutex> lock(const_cast<redgpu_group *>(g)->hostMu);
+    for (size_t k = 1; k < G; ++k) g->workers[k - 1]->post([&work, k] { work(k); });
+    work(0);
+    for (size_t k = 1; k < G; ++k) g->workers[k - 1]->wait();
+  }
   for (size_t k = 0; k < G; ++k)
     if (rcs[k] != REDGPU_OK) return fail(rcs[k], "device shard " + std::to_string(k) + ": " + msgs[k]);
   return REDGPU_OK;

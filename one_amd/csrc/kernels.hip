@@ -277,20 +277,51 @@ __device__ __forceinline__ void walkBytes(const uint8_t *p, uint64_t from, uint6
 #pragma unroll 1
     for (uint32_t c = 0; c < nc; ++c) {
       const uint4 v = c == 0 ? b0 : c == 1 ? b1 : c == 2 ? b2 : b3;
-      // words rolled, bytes unrolled: keeps the body (and its registers) small
-#pragma unroll 1
-      for (int wi = 0; wi < 4; ++wi) {
-        const uint32_t word = wi == 0 ? v.x : wi == 1 ? v.y : wi == 2 ? v.z : v.w;
+      // the 16 byte steps of a chunk straight-line (round 1 rolled the words to keep the body
+      // small: the dynamic word selects and the loop cost more than the code they saved)
+      const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+      const uint64_t at = i + 16 * c;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (!f((word >> (8 * k)) & 0xffu, i + 16 * c + 4 * wi + k)) return;
-      }
+      for (int k = 0; k < 16; ++k)
+        if (!f((words[k >> 2] >> (8 * (k & 3))) & 0xffu, at + k)) return;
     }
     i += 16ull * nc;
     want = 4;
   }
   for (; i < n; ++i)
     if (!f(uint32_t(p[i]), i)) return;
+}
+
+// Every byte of p[0..n) to f(byte, index), no early exit, straight-line: 64-byte trips of four
+// back-to-back requests, 16 byte steps per chunk unrolled (no rolled word loop, no per-byte
+// branch).  For walks that never leave before the end of the line - matchAll over a DFA whose
+// pure dead ends are absorbing: past one nothing accepts and nothing is recorded.
+template <class F>
+__device__ __forceinline__ void walkAllBytes(const uint8_t *p, uint64_t n, F &&f) {
+  uint64_t i = 0;
+  auto chunk = [&](const uint4 &v, uint64_t at) {
+    const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) f((words[k >> 2] >> (8 * (k & 3))) & 0xffu, at + k);
+  };
+#pragma unroll 1
+  while (i + 64 <= n) {
+    const uint4 b0 = *reinterpret_cast<const uint4 *>(p + i);
+    const uint4 b1 = *reinterpret_cast<const uint4 *>(p + i + 16);
+    const uint4 b2 = *reinterpret_cast<const uint4 *>(p + i + 32);
+    const uint4 b3 = *reinterpret_cast<const uint4 *>(p + i + 48);
+    chunk(b0, i);
+    chunk(b1, i + 16);
+    chunk(b2, i + 32);
+    chunk(b3, i + 48);
+    i += 64;
+  }
+#pragma unroll 1
+  while (i + 16 <= n) {
+    chunk(*reinterpret_cast<const uint4 *>(p + i), i);
+    i += 16;
+  }
+  for (; i < n; ++i) f(uint32_t(p[i]), i);
 }
 
 // walkBytes that also hands f the NEXT byte (kNoPeek when it is not in the chunk in hand or
@@ -1543,7 +1574,7 @@ k_collect(DevDfa d, Batch b, uint64_t cap, uint64_t *counts) {
 // record (:749-752); a non-accepting byte resets the run (:757) and a pure dead end stops the
 // walk (:755-756).  The record being extended keeps its end in a register and is flushed when
 // the run closes, instead of re-storing it per byte.
-template <class T>
+template <class T, bool NOEXIT = false>
 __device__ uint64_t matchAllLane(const T &tab, const LaneCtx &c, const uint8_t *p, uint64_t n,
                                  bool lead, uint64_t cap, int32_t *res, uint64_t *st,
                                  uint64_t *en) {
@@ -1551,7 +1582,7 @@ __device__ uint64_t matchAllLane(const T &tab, const LaneCtx &c, const uint8_t *
   uint32_t s = c.init;
   int32_t prev = 0;
   uint64_t matchStart = 0, found = 0, curEnd = 0;
-  walkBytes(p, 0, n, [&](uint32_t byte, uint64_t idx) {
+  auto step = [&](uint32_t byte, uint64_t idx) -> bool {
     const uint32_t was = s;
     s = tab.next(s, byte);
     if (was == c.init && s != was) matchStart = idx;
@@ -1568,11 +1599,15 @@ __device__ uint64_t matchAllLane(const T &tab, const LaneCtx &c, const uint8_t *
       }
       curEnd = idx + 1;
     } else {
-      if (s < c.nPureDead) return false;
+      if (!NOEXIT && s < c.nPureDead) return false;
       prev = 0;
     }
     return true;
-  });
+  };
+  if constexpr (NOEXIT)
+    walkAllBytes(p, n, [&](uint32_t byte, uint64_t idx) { (void)step(byte, idx); });
+  else
+    walkBytes(p, 0, n, step);
   if (found && found - 1 < cap && en) en[found - 1] = curEnd;
   return found;
 }
@@ -1606,9 +1641,14 @@ k_matchall(DevDfa d, Batch b, uint64_t cap, uint64_t *counts, int lead) {
       p = b.data + line * b.stride;
       n = b.stride;
     }
-    counts[line] = matchAllLane(tab, c, p, n, lead != 0, cap, b.result + line * cap,
-                                b.start ? b.start + line * cap : nullptr,
-                                b.end ? b.end + line * cap : nullptr);
+    // pure dead ends that are absorbing: the straight-line walk (nothing can happen past one)
+    counts[line] = d.deadAbsorbing
+                       ? matchAllLane<Tab<KIND>, true>(tab, c, p, n, lead != 0, cap, b.result + line * cap,
+                                                       b.start ? b.start + line * cap : nullptr,
+                                                       b.end ? b.end + line * cap : nullptr)
+                       : matchAllLane(tab, c, p, n, lead != 0, cap, b.result + line * cap,
+                                      b.start ? b.start + line * cap : nullptr,
+                                      b.end ? b.end + line * cap : nullptr);
   }
 }
 

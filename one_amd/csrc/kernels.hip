@@ -637,10 +637,27 @@ __device__ int32_t matchLane(const T &tab, const LaneCtx &c, const uint8_t *p, u
   return w.finish(style, startOut, endOut);
 }
 
+// check<styLast / styFull> without a leader over a DFA whose dead ends are absorbing (and that is
+// not an early-death DFA): every byte, no exit test, no per-byte result lookup - styFull is the
+// final state's result, styLast the last accepting state's (include/Matcher.h:382-409; an empty
+// input answers with the initial state's result either way).
+template <class T, bool FULL>
+__device__ int32_t checkLeanLane(const T &tab, const LaneCtx &c, const uint8_t *p, uint64_t n) {
+  uint32_t s = c.init, accS = 0;
+  bool any = false;
+  walkAllBytes(p, n, [&](uint32_t byte, uint64_t) {
+    s = tab.next(s, byte);
+    if (!FULL && s >= c.firstAccept) { accS = s; any = true; }
+  });
+  if (n == 0) return c.resultOf(c.init);
+  if (FULL) return c.resultOf(s);
+  return any ? c.res[accS] : 0;
+}
+
 // match<styLast> through the lean walk: the result table is read once, after the loop - with
 // c.res[s] inside it every accepting step is a second dependent global load on the wave's
 // critical path (a table in L2: two round trips per byte instead of one)
-template <class T>
+template <class T, bool NOEXIT = false>
 __device__ int32_t matchLastLane(const T &tab, const LaneCtx &c, const uint8_t *p, uint64_t n,
                                  bool lead, uint64_t &startOut, uint64_t &endOut) {
   startOut = 0;
@@ -648,7 +665,10 @@ __device__ int32_t matchLastLane(const T &tab, const LaneCtx &c, const uint8_t *
   if (lead && !lookingAt(c, p, 0, n)) return 0;
   LastWalk w;
   w.begin(c);
-  walkBytes(p, 0, n, [&](uint32_t byte, uint64_t idx) { return w.step(tab, c, kStyLast, byte, idx); });
+  if constexpr (NOEXIT)  // absorbing dead ends, not an early-death DFA: every byte, no exit test
+    walkAllBytes(p, n, [&](uint32_t byte, uint64_t idx) { (void)w.step(tab, c, kStyLast, byte, idx); });
+  else
+    walkBytes(p, 0, n, [&](uint32_t byte, uint64_t idx) { return w.step(tab, c, kStyLast, byte, idx); });
   return w.finish(c, kStyLast, startOut, endOut);
 }
 
@@ -890,13 +910,19 @@ k_generic(DevDfa d, Batch b, int style, int lead) {
       n = b.stride;
     }
     if (verb == kCheck) {
-      b.result[line] = checkLane(tab, c, p, n, style, lead != 0);
+      const bool lean = !lead && d.deadAbsorbing && !d.earlyDeath;
+      b.result[line] = lean && style == kStyFull   ? checkLeanLane<Tab<KIND>, true>(tab, c, p, n)
+                       : lean && style == kStyLast ? checkLeanLane<Tab<KIND>, false>(tab, c, p, n)
+                                                   : checkLane(tab, c, p, n, style, lead != 0);
     } else if (verb == kScan) {
       b.result[line] = scanLane(tab, c, p, n, style, lead != 0);
     } else {
       uint64_t st, en;
       b.result[line] = verb == kSearch ? searchLane(tab, c, p, n, style, lead != 0, st, en)
-                       : style == kStyLast ? matchLastLane(tab, c, p, n, lead != 0, st, en)
+                       : style == kStyLast
+                           ? (d.deadAbsorbing && !d.earlyDeath
+                                  ? matchLastLane<Tab<KIND>, true>(tab, c, p, n, lead != 0, st, en)
+                                  : matchLastLane(tab, c, p, n, lead != 0, st, en))
                                            : matchLane(tab, c, p, n, style, lead != 0, st, en);
       if (b.start) b.start[line] = st;
       if (b.end) b.end[line] = en;
@@ -1685,11 +1711,15 @@ k_advance(DevDfa d, Batch b, uint32_t *state) {
     }
     uint32_t s = state[line];
     if (s >= d.nStates) s = d.init;  // REDGPU_STATE_INITIAL (and any token that is not ours)
-    const bool stopDead = d.deadAbsorbing != 0;  // an absorbing dead end stays put: stop reading
-    walkBytes(p, 0, n, [&](uint32_t byte, uint64_t) {
-      s = tab.next(s, byte);
-      return !(stopDead && s < d.nPureDead);
-    });
+    if (d.deadAbsorbing && d.earlyDeath) {
+      // an absorbing dead end stays put: stop reading (anchored patterns die in their first bytes)
+      walkBytes(p, 0, n, [&](uint32_t byte, uint64_t) {
+        s = tab.next(s, byte);
+        return s >= d.nPureDead;
+      });
+    } else {
+      walkAllBytes(p, n, [&](uint32_t byte, uint64_t) { s = tab.next(s, byte); });
+    }
     state[line] = s;
     b.result[line] = c.resultOf(s);
   }

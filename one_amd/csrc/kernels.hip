@@ -936,19 +936,24 @@ k_generic(DevDfa d, Batch b, int style, int lead) {
 // most lines are in a pure dead end after a byte or two and the others walk a whole signature.
 // k_generic gives a lane a line: a wave then holds 64 lines until its slowest one is done (half
 // of its lanes idle on configs[3]) and pays the line's memory round trips - offsets, first
-// bytes, next trip - one behind the other.  Here a workgroup takes 4 lines per lane at a time
+// bytes, next trip - one behind the other.  Here a workgroup takes LPL lines per lane at a time
 // and
-//   1. PROBES them: offsets and the first 16 bytes of all four lines are requested together, then
-//      each is walked for kEarlyProbe bytes.  A line that is done by then (pure dead end, an
+//   1. PROBES them: offsets and the first PC x 16 bytes of all of them are requested together,
+//      then each is walked through those bytes from registers (eight at a time; a wave moves on
+//      once none of its lanes is alive).  A line that is done by then (pure dead end, an
 //      early-exit style, end of line) stores its Outcome; a survivor's loop state (MatchWalk) is
 //      parked in an LDS queue (one wave-aggregated atomic per wave and line slot);
 //   2. DRAINS the queue: the survivors, now dense, are dealt out again - every lane resumes one
-//      at byte kEarlyProbe and walks it to its end.
+//      behind the bytes the probe held and walks it to its end.
 // Same lane code as matchLane (MatchWalk::step / finish), so the results are the reference's
 // for every style; the table kinds are the LDS-resident ones.
 // =========================================================================================
-constexpr uint32_t kEarlyProbe = 8;
-constexpr int kEarlyThreads = 512;
+// bytes of a line (>= 16 long) the probe holds in registers: whole 16-byte pieces, at most PC
+template <int PC>
+__device__ __forceinline__ uint32_t earlyHave(uint64_t n) {
+  const uint64_t pieces = n >> 4;
+  return 16u * uint32_t(pieces < uint64_t(PC) ? pieces : uint64_t(PC));
+}
 
 // LPL = lines per lane and round; WPS = waves per SIMD the register allocation must allow: LDS
 // decides how many workgroups share a CU, and occupancy is what this kernel lives on.  Measured on
@@ -959,15 +964,20 @@ constexpr int kEarlyThreads = 512;
 // the launch moves ~2.2 GB through L2 - nearly every cache line of the input is touched by a line
 // start, and again when a survivor is drained - so it sits near the memory system's rate for
 // scattered 128-byte requests, not on the latency of any one of them).
-template <int KIND, class WALK, int LPL, int WPS>
-__global__ void __launch_bounds__(kEarlyThreads, WPS)
+// PC = 16-byte pieces of a line the probe holds: all 16 bytes of the first piece walked in the
+// probe (it was 8: the lines that die between byte 8 and 16 no longer pay a queue slot and a
+// reload) 415 -> 345 us; two or four pieces (fewer reloads: 1.6 GB instead of 2.1 GB missing L2)
+// 346 / 377 us - no faster; 1024-thread workgroups (32 waves per CU) 363 us; the drain's next
+// two pieces requested together 360 us (scripts/gpu_run17.sh).
+template <int KIND, class WALK, int LPL, int WPS, int PC, int THREADS>
+__global__ void __launch_bounds__(THREADS, WPS)
 k_early(DevDfa d, Batch b, int style, int lead) {
-  constexpr uint32_t kEarlyChunk = kEarlyThreads * LPL;
+  constexpr uint32_t kEarlyChunk = THREADS * LPL;
   constexpr uint32_t L = LPL;
   extern __shared__ __align__(16) uint8_t lds[];
   // (no LDS copy of the result table: this kernel reads it once per line, and the space buys a
   // third workgroup per CU)
-  const Tab<KIND> tab = stageTab<KIND, kEarlyThreads, false>(d, lds);
+  const Tab<KIND> tab = stageTab<KIND, THREADS, false>(d, lds);
   uint4 *queue = reinterpret_cast<uint4 *>(lds + 512 + ((tableOnlyBytes<KIND>(d) + 15) & ~size_t(15)));
   __shared__ uint32_t qCount;
   LaneCtx c;
@@ -1004,16 +1014,19 @@ k_early(DevDfa d, Batch b, int style, int lead) {
     __syncthreads();
     // ---- 1. probe: offsets and first bytes of all the lane's lines requested together --------
     uint64_t o[L], n[L];
-    uint4 head[L];
+    uint4 head[L][PC];
 #pragma unroll
     for (uint32_t k = 0; k < L; ++k)
-      spanOf(chunk * kEarlyChunk + uint64_t(k) * kEarlyThreads + threadIdx.x, o[k], n[k]);
+      spanOf(chunk * kEarlyChunk + uint64_t(k) * THREADS + threadIdx.x, o[k], n[k]);
 #pragma unroll
     for (uint32_t k = 0; k < L; ++k)
-      head[k] = n[k] >= 16 ? *reinterpret_cast<const uint4 *>(b.data + o[k]) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (uint32_t j = 0; j < uint32_t(PC); ++j)
+        head[k][j] = n[k] >= 16 * (j + 1) ? *reinterpret_cast<const uint4 *>(b.data + o[k] + 16 * j)
+                                          : make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (uint32_t k = 0; k < L; ++k) {
-      const uint64_t line = chunk * kEarlyChunk + uint64_t(k) * kEarlyThreads + threadIdx.x;
+      const uint64_t line = chunk * kEarlyChunk + uint64_t(k) * THREADS + threadIdx.x;
       const bool valid = line < b.n;
       const uint8_t *p = b.data + o[k];
       WALK w;
@@ -1027,11 +1040,22 @@ k_early(DevDfa d, Batch b, int style, int lead) {
       }
       if (alive) {
         if (n[k] >= 16) {
-          const uint32_t words[2] = {head[k].x, head[k].y};
+          const uint32_t have = earlyHave<PC>(n[k]);
 #pragma unroll
-          for (uint32_t i = 0; i < kEarlyProbe; ++i)
-            if (alive) alive = w.step(tab, c, style, (words[i >> 2] >> (8 * (i & 3))) & 0xffu, i);
-          if (!alive) store(line, w);  // done within the probe; the others have bytes left
+          for (uint32_t g = 0; g < 2 * uint32_t(PC); ++g) {
+            // past the probe proper only the survivors walk on, from the bytes already in registers
+            if (g > 0 && !__builtin_amdgcn_ballot_w64(alive && 8 * g < have)) break;
+            const uint4 &h = head[k][g >> 1];
+            const uint32_t words[2] = {g & 1 ? h.z : h.x, g & 1 ? h.w : h.y};
+#pragma unroll
+            for (uint32_t i = 0; i < 8; ++i)
+              if (alive && 8 * g < have)
+                alive = w.step(tab, c, style, (words[i >> 2] >> (8 * (i & 3))) & 0xffu, 8 * g + i);
+          }
+          if (!alive || have == n[k]) {  // done within the probe; the others have bytes left
+            store(line, w);
+            alive = false;
+          }
         } else {  // a short line: all of it, byte by byte
           for (uint64_t i = 0; i < n[k] && alive; ++i) alive = w.step(tab, c, style, p[i], i);
           store(line, w);
@@ -1047,21 +1071,21 @@ k_early(DevDfa d, Batch b, int style, int lead) {
         if (alive) {
           const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32),
                                     __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
-          queue[base + rank] = w.pack(uint32_t(k * kEarlyThreads + threadIdx.x));
+          queue[base + rank] = w.pack(uint32_t(k * THREADS + threadIdx.x));
         }
       }
     }
     __syncthreads();
     // ---- 2. drain: the survivors, dense again, walked to their end ---------------------------
     const uint32_t qn = qCount;
-    for (uint32_t q = threadIdx.x; q < qn; q += kEarlyThreads) {
+    for (uint32_t q = threadIdx.x; q < qn; q += THREADS) {
       const uint4 en = queue[q];
       WALK w;
       w.unpack(en);
       const uint64_t ln = chunk * kEarlyChunk + (en.x & 0xfffu);
       uint64_t oo, nl;
       spanOf(ln, oo, nl);
-      walkBytes(b.data + oo, kEarlyProbe, nl,
+      walkBytes(b.data + oo, earlyHave<PC>(nl), nl,
                 [&](uint32_t byte, uint64_t idx) { return w.step(tab, c, style, byte, idx); });
       store(ln, w);
     }
@@ -1678,6 +1702,134 @@ k_matchall(DevDfa d, Batch b, uint64_t cap, uint64_t *counts, int lead) {
   }
 }
 
+// =========================================================================================
+// k_matchall_blocks: matchAllCore (include/Matcher.h:711-766) in two phases per block of a line.
+//
+// matchAllLane tests "did this byte accept, and is it a new record" at every byte: with 64 lanes
+// some lane nearly always says yes (SYN-256: one state in seven accepts), so the wave runs the
+// record path - result lookup, compare, three scattered stores - at every byte of every line.
+// Here a lane takes its line in blocks of kPos positions and
+//   A. WALKS the block straight-line with nothing data-dependent in it: per byte the lookup, one
+//      bit "accepting" and one bit "is the initial state" shifted into two masks, and the state
+//      itself packed into a word that goes to LDS every fourth (second) byte - the lane's kPos
+//      states, at a lane-interleaved address (no bank conflicts);
+//   B. VISITS the accepting positions of the block only (a per-lane loop over the set bits of
+//      the mask): the state comes back from LDS, its result from the LDS result table, "same run
+//      as the byte before" from the mask, the record's start from the highest "left the initial
+//      state" bit at or below the position (Matcher.h:726-731).  The wave's trip count is the
+//      largest accept count among its 64 lines' blocks, not the block length.
+// Requires absorbing pure dead ends (nothing accepts past one, so not leaving at :755-756 changes
+// nothing), an LDS-resident table kind and the result table in LDS.  W = bytes per staged state.
+// =========================================================================================
+template <int KIND, int THREADS, int W>
+__global__ void __launch_bounds__(THREADS)
+k_matchall_blocks(DevDfa d, Batch b, uint64_t cap, uint64_t *counts, int lead) {
+  constexpr uint32_t kPos = 64 / W;       // positions per block: 64 bytes of staged states per lane
+  constexpr uint32_t kPerWord = 4 / W;    // states per staged 32-bit word
+  extern __shared__ __align__(16) uint8_t lds[];
+  const Tab<KIND> tab = stageTab<KIND, THREADS>(d, lds);
+  LaneCtx c{lds, lds + 256, resOf<KIND>(d, lds), d.init, d.leaderNext, d.nPureDead, d.firstAccept,
+            d.leaderLen};
+  uint32_t *stage = reinterpret_cast<uint32_t *>(lds + 512 + ((ldsTableBytes<KIND>(d) + 15) & ~size_t(15)));
+  const uint8_t *stageBytes = reinterpret_cast<const uint8_t *>(stage);
+  const uint64_t step = uint64_t(gridDim.x) * THREADS;
+  for (uint64_t line = uint64_t(blockIdx.x) * THREADS + threadIdx.x; line < b.n; line += step) {
+    const uint8_t *p;
+    uint64_t n;
+    if (b.offsets) {
+      const uint64_t o = b.offsets[line];
+      p = b.data + o;
+      n = b.offsets[line + 1] - o;
+      n = n >= b.stride ? n - b.stride : 0;  // stride = trailing bytes to drop (ragged)
+    } else {
+      p = b.data + line * b.stride;
+      n = b.stride;
+    }
+    int32_t *res = b.result + line * cap;
+    uint64_t *st = b.start ? b.start + line * cap : nullptr;
+    uint64_t *en = b.end ? b.end + line * cap : nullptr;
+    if (lead && !lookingAt(c, p, 0, n)) n = 0;  // (found stays 0)
+    uint32_t s = c.init;
+    int32_t prevR = 0;       // result at the last position of the block before, 0 if it did not accept
+    uint64_t matchStart = 0, found = 0, curEnd = 0;
+    for (uint64_t base = 0; base < n; base += kPos) {
+      const uint64_t rem = n - base;
+      const uint32_t nq = rem >= kPos ? kPos / 16 : uint32_t(rem >> 4);  // whole 16-byte pieces
+      uint64_t acc = 0, ini = 0;
+      const uint64_t wasInit = s == c.init ? 1u : 0u;
+      // ---- A: the walk -------------------------------------------------------------------------
+      uint4 piece[kPos / 16];
+#pragma unroll
+      for (uint32_t q = 0; q < kPos / 16; ++q)
+        piece[q] = q < nq ? *reinterpret_cast<const uint4 *>(p + base + 16 * q) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (uint32_t q = 0; q < kPos / 16; ++q) {
+        if (q < nq) {
+          const uint32_t words[4] = {piece[q].x, piece[q].y, piece[q].z, piece[q].w};
+          uint32_t packed = 0;
+#pragma unroll
+          for (uint32_t k = 0; k < 16; ++k) {
+            const uint32_t pos = 16 * q + k;
+            s = tab.next(s, (words[k >> 2] >> (8 * (k & 3))) & 0xffu);
+            acc |= s >= c.firstAccept ? 1ull << pos : 0ull;
+            ini |= s == c.init ? 1ull << pos : 0ull;
+            packed |= s << (8 * W * (pos % kPerWord));
+            if (pos % kPerWord == kPerWord - 1) {
+              stage[(pos / kPerWord) * THREADS + threadIdx.x] = packed;
+              packed = 0;
+            }
+          }
+        }
+      }
+      uint32_t cnt = 16 * nq;
+      if (cnt < kPos && cnt < rem) {  // the last < 16 bytes of the line
+        const uint32_t last = uint32_t(rem);  // < kPos here
+        for (; cnt < last; ++cnt) {
+          s = tab.next(s, uint32_t(p[base + cnt]));
+          acc |= uint64_t(s >= c.firstAccept) << cnt;
+          ini |= uint64_t(s == c.init) << cnt;
+          uint8_t *slot = reinterpret_cast<uint8_t *>(stage) +
+                          (((cnt / kPerWord) * THREADS + threadIdx.x) << 2) + W * (cnt % kPerWord);
+          if (W == 1) *slot = uint8_t(s);
+          else *reinterpret_cast<uint16_t *>(slot) = uint16_t(s);
+        }
+      }
+      // ---- B: the accepting positions ----------------------------------------------------------
+      const uint64_t valid = cnt >= 64 ? ~0ull : (1ull << cnt) - 1;
+      const uint64_t esc = (((ini << 1) | wasInit) & ~ini) & valid;  // "left the initial state" here
+      uint64_t todo = acc;
+      const bool lastAcc = prevR != 0;
+      while (todo) {
+        const uint32_t i = uint32_t(__builtin_ctzll(todo));
+        todo &= todo - 1;
+        const bool contig = i ? ((acc >> (i - 1)) & 1u) != 0 : lastAcc;
+        const uint8_t *slot = stageBytes + (((i / kPerWord) * THREADS + threadIdx.x) << 2) +
+                              W * (i % kPerWord);
+        const uint32_t si = W == 1 ? uint32_t(*slot) : uint32_t(*reinterpret_cast<const uint16_t *>(slot));
+        const int32_t r = c.res[si];
+        if (r != (contig ? prevR : 0)) {
+          if (found && found - 1 < cap && en) en[found - 1] = curEnd;
+          if (found < cap) {
+            res[found] = r;
+            if (st) {
+              const uint64_t m = esc & ((2ull << i) - 1);
+              st[found] = m ? base + 63 - uint32_t(__builtin_clzll(m)) : matchStart;
+            }
+          }
+          ++found;
+        }
+        curEnd = base + i + 1;
+        prevR = r;
+      }
+      // carried into the next block: does its first position continue a run, and the last escape
+      if (!(cnt && ((acc >> (cnt - 1)) & 1u))) prevR = 0;
+      if (esc) matchStart = base + 63 - uint32_t(__builtin_clzll(esc));
+    }
+    if (found && found - 1 < cap && en) en[found - 1] = curEnd;
+    counts[line] = found;
+  }
+}
+
 // StatefulMatcher::advance (include/Matcher.h:770-792, lib/Matcher.cpp:106-158) over a whole
 // chunk per line: state[line] is the matcher's state_ (a device state index; REDGPU_STATE_INITIAL
 // = a freshly constructed matcher, lib/Matcher.cpp:113-136), advanced by every byte of the
@@ -2165,24 +2317,24 @@ hipError_t launchGeneric(const DevDfa &d, const Batch &b, int verb, int style, i
   return hipGetLastError();
 }
 
-template <int KIND, class WALK, int LPL, int WPS>
+template <int KIND, class WALK, int LPL, int WPS, int PC = 1, int THREADS = 512>
 hipError_t launchEarlyV(const DevDfa &d, const Batch &b, int style, int lead, const LaunchCfg &cfg,
                         hipStream_t stream) {
   const size_t tabBytes = (tableOnlyBytes<KIND>(d) + 15) & ~size_t(15);
-  const size_t ldsBytes = 512 + tabBytes + size_t(kEarlyThreads) * LPL * 16;
-  hipError_t e = setLds(k_early<KIND, WALK, LPL, WPS>, ldsBytes);
+  const size_t ldsBytes = 512 + tabBytes + size_t(THREADS) * LPL * 16;
+  hipError_t e = setLds(k_early<KIND, WALK, LPL, WPS, PC, THREADS>, ldsBytes);
   if (e != hipSuccess) return e;
   // as many workgroups per CU as LDS and the register budget allow (their probe / drain phases
   // overlap each other's memory round trips)
   uint64_t perCu = (160 * 1024) / (ldsBytes + 256);
-  const uint64_t byRegs = uint64_t(WPS) * 4 / (kEarlyThreads / 64);
+  const uint64_t byRegs = uint64_t(WPS) * 4 / (THREADS / 64);
   perCu = perCu > byRegs ? byRegs : perCu;
   if (perCu < 1) perCu = 1;
-  const uint64_t chunk = uint64_t(kEarlyThreads) * LPL;
+  const uint64_t chunk = uint64_t(THREADS) * LPL;
   const uint64_t chunks = (b.n + chunk - 1) / chunk;
   uint64_t blocks = uint64_t(cfg.numCUs) * perCu;
   if (blocks > chunks) blocks = chunks;
-  hipLaunchKernelGGL((k_early<KIND, WALK, LPL, WPS>), dim3(uint32_t(blocks)), dim3(kEarlyThreads),
+  hipLaunchKernelGGL((k_early<KIND, WALK, LPL, WPS, PC, THREADS>), dim3(uint32_t(blocks)), dim3(THREADS),
                      ldsBytes, stream, d, b, style, lead);
   return hipGetLastError();
 }
@@ -2218,6 +2370,36 @@ hipError_t launchMatchAllK(const DevDfa &d, const Batch &b, uint64_t cap, uint64
                            int lead, const LaunchCfg &cfg, hipStream_t stream) {
   constexpr bool kLds = Tab<KIND>::kInLds || KIND == REDGPU_TAB_HOT_ROWS;
   constexpr int kThreads = kLds ? 1024 : 256;
+  if constexpr (Tab<KIND>::kInLds) {
+    // the block-wise form: table + results + 64 bytes of staged states per lane in LDS
+    const size_t tab = 512 + ((ldsTableBytes<KIND>(d) + 15) & ~size_t(15));
+    if (!cfg.forceGeneric && d.deadAbsorbing && resStaged<KIND>(d) && d.nStates <= 65535 &&
+        tab + 512 * 64 + 256 <= size_t(160) * 1024) {
+      // 1024- or 512-thread workgroups, whichever keeps more lanes resident on a CU
+      auto resident = [&](uint64_t threads) -> uint64_t {
+        uint64_t wgs = (size_t(160) * 1024) / (tab + threads * 64 + 256);
+        if (wgs > 2048 / threads) wgs = 2048 / threads;
+        return wgs;
+      };
+      const bool big = resident(1024) * 1024 >= resident(512) * 512;
+      const int threads = big ? 1024 : 512;
+      const size_t ldsBytes = tab + size_t(threads) * 64;
+      uint64_t blocks = (b.n + threads - 1) / threads;
+      const uint64_t perCu = resident(uint64_t(threads));
+      if (blocks > uint64_t(cfg.numCUs) * perCu) blocks = uint64_t(cfg.numCUs) * perCu;
+#define MAB_LAUNCH(T, W)                                                                     \
+  do {                                                                                         \
+    hipError_t e2 = setLds(k_matchall_blocks<KIND, T, W>, ldsBytes);                          \
+    if (e2 != hipSuccess) return e2;                                                           \
+    hipLaunchKernelGGL((k_matchall_blocks<KIND, T, W>), dim3(uint32_t(blocks)), dim3(T),      \
+                       ldsBytes, stream, d, b, cap, counts, lead);                             \
+  } while (0)
+      if (d.nStates <= 256) { if (big) MAB_LAUNCH(1024, 1); else MAB_LAUNCH(512, 1); }
+      else { if (big) MAB_LAUNCH(1024, 2); else MAB_LAUNCH(512, 2); }
+#undef MAB_LAUNCH
+      return hipGetLastError();
+    }
+  }
   const size_t ldsBytes = 512 + ldsTableBytes<KIND>(d);
   hipError_t e = setLds(k_matchall<KIND, kThreads>, ldsBytes);
   if (e != hipSuccess) return e;

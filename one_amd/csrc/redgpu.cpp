@@ -264,7 +264,7 @@ int collectDev(const redgpu_dfa *dfa, int listVerb, const uint8_t *data, const u
   DeviceScope scope(dfa->im->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   Batch b{data, offsets, stride, n, result, start, end};
-  LaunchCfg cfg{dfa->numCUs, 0};
+  LaunchCfg cfg{dfa->numCUs, (dfa->flags & REDGPU_F_FORCE_GENERIC) ? 1 : 0};
   hipError_t e = listVerb == kListCollect
                      ? launchCollect(dfa->im->dev, b, cap, counts, cfg, stream)
                      : launchMatchAll(dfa->im->dev, b, cap, counts, listVerb == kListMatchAllLeader,

@@ -15,6 +15,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 HOT_BIAS = len(sys.argv) > 3 and sys.argv[3] in ("hot", "cls")  # big DFAs, block-multiple strides
 CLS_BIAS = len(sys.argv) > 3 and sys.argv[3] == "cls"           # ... of the class-table size
+LISTS = len(sys.argv) > 3 and sys.argv[3] == "lists"            # only the record-list verbs
 rng = np.random.default_rng(seed)
 ALPHA = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz0123456789 ./:-_=&?%@[]", dtype=np.uint8)
 
@@ -121,7 +122,9 @@ for case in range(cases):
     desc = (case, name, {k: (v if not hasattr(v, "shape") else "offsets[%d]" % (len(v) - 1)) for k, v in shape.items()}, flags, exe.info["table_kind"])
     verbs = (["match", "check", "advance", "match", "check"] if HOT_BIAS else
              ["match", "check", "scan", "search", "advance", "match_all", "collect", "replace"])
-    for verb in (rng.choice(verbs, 3) if HOT_BIAS else rng.choice(verbs, 3, replace=False)):
+    if LISTS:
+        verbs = ["match_all", "collect", "match_all"]
+    for verb in (rng.choice(verbs, 3) if HOT_BIAS or LISTS else rng.choice(verbs, 3, replace=False)):
         sty = int(rng.choice([4, 5, 4, 5, 1, 2, 3])) if HOT_BIAS else int(rng.integers(1, 6))
         lead = int(rng.integers(0, 2))
         kw = dict(shape)

@@ -1600,18 +1600,49 @@ k_collect(DevDfa d, Batch b, uint64_t cap, uint64_t *counts) {
       p = b.data + line * b.stride;
       n = b.stride;
     }
+    const StartFilter flt{c.startWord[0], c.startCount[0] <= 4 ? c.startCount[0] : 0u,
+                          c.start2Word[0], c.start2Count[0] <= 4 ? c.start2Count[0] : 0u, false};
     uint64_t found = 0, pos = 0;
     while (pos < n) {
-      uint64_t st, en;
-      const int32_t r = searchLane(tab, c, p + pos, n - pos, kStyLast, false, st, en);
-      if (!(r > 0)) break;
+      // search<styLast,false> from pos (Matcher.h:557-640), lean: an attempt carries the state,
+      // the last accepting state, its end and the last "left the initial state" position; the
+      // result table is read once per match.  Attempts that outlive a few bytes go on in
+      // 16-byte requests (a dense DFA's attempt runs to the end of the line).
+      bool got = false;
+      uint32_t accS = 0;
+      uint64_t mS = 0, mE = 0;
+      walkBytesPeek(p, pos, n, flt, [] {}, [&](uint32_t byte, uint64_t i, uint32_t nextByte) -> bool {
+        uint32_t st = tab.next(c.init, byte);
+        bool any = false;
+        uint64_t ms = i, me = i;
+        uint32_t aS = 0;
+        if (st >= c.firstAccept) { aS = st; me = i + 1; any = true; }
+        else if (st < c.nPureDead) return true;
+        else if (nextByte != kNoPeek && tab.next(st, nextByte) < c.nPureDead) return true;
+        auto stepOne = [&](uint32_t b2, uint64_t q) -> bool {
+          const uint32_t was = st;
+          st = tab.next(st, b2);
+          if (was == c.init && st != was) ms = q;
+          const bool acc = st >= c.firstAccept;
+          if (acc) { aS = st; me = q + 1; any = true; }
+          return acc || st >= c.nPureDead;
+        };
+        uint64_t q = i + 1;
+        bool alive = true;
+        for (uint32_t k = 0; k < 6 && q < n && alive; ++k, ++q) alive = stepOne(uint32_t(p[q]), q);
+        if (alive) walkBytes(p, q, n, stepOne);
+        if (!any) return true;
+        got = true; accS = aS; mS = ms; mE = me;
+        return false;
+      });
+      if (!got) break;
       if (found < cap) {
-        b.result[line * cap + found] = r;
-        if (b.start) b.start[line * cap + found] = pos + st;
-        if (b.end) b.end[line * cap + found] = pos + en;
+        b.result[line * cap + found] = c.res[accS];
+        if (b.start) b.start[line * cap + found] = mS;
+        if (b.end) b.end[line * cap + found] = mE;
       }
       ++found;
-      pos += en;
+      pos = mE;
     }
     counts[line] = found;
   }

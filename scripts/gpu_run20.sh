@@ -1,0 +1,11 @@
+#!/bin/bash
+# attempt walks of scan / search / collect on 16-byte requests: parity, then the benchmarks
+set -u
+mkdir -p gpurun_out
+timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py -q -x -k "scan or search or collect or all_verbs or kat or omnibus or replace" > gpurun_out/r2_tmp.log 2>&1 || { tail -40 gpurun_out/r2_tmp.log; exit 1; }
+tail -1 gpurun_out/r2_tmp.log
+timeout -k 10 500 python3 scripts/fuzz_gpu.py 250 11 > gpurun_out/r2_fuzz.log 2>&1 || { tail -30 gpurun_out/r2_fuzz.log; exit 1; }
+tail -1 gpurun_out/r2_fuzz.log
+timeout -k 10 300 python3 scripts/bench_scan.py 2>&1 | grep -v amdgpu.ids
+timeout -k 10 300 python3 scripts/bench_lists.py 2>&1 | grep -v amdgpu.ids | grep "collect\|matchAll"
+timeout -k 10 300 python3 scripts/bench_generic.py 2>&1 | grep -v amdgpu.ids

@@ -1733,6 +1733,58 @@ k_matchall(DevDfa d, Batch b, uint64_t cap, uint64_t *counts, int lead) {
   }
 }
 
+// One byte of k_matchall_blocks' walk over a fused u8 table at LDS offset 512 (the address is
+// (state << 8) | byte, formed by v_perm_b32), as ONE asm statement so the lookup's round trip
+// is covered by the bookkeeping of the state in hand - the state BEFORE this byte, i.e. the
+// masks and the packed word run one position behind: "accepting" and "is the initial state"
+// are shifted into accR / iniR by add-with-carry (first position = highest bit), the state
+// into `packed` from the top (first state = lowest byte).  The two compares write SGPR pairs
+// that the add-with-carrys read three instructions later (gfx950 wants two wait states
+// between a VALU writing an SGPR and a VALU reading it).
+template <bool BOOK>
+__device__ __forceinline__ void mabStep(uint32_t &s, uint32_t w, uint32_t sel, uint32_t &accR,
+                                        uint32_t &iniR, uint32_t &packed, uint32_t T,
+                                        uint32_t init) {
+  uint32_t a, t;
+  uint64_t m, i2, junk;
+  if constexpr (BOOK) {
+    asm volatile("v_perm_b32 %[a], %[s], %[w], %[sel]\n\t"
+                 "ds_read_u8 %[t], %[a] offset:512\n\t"
+                 "v_cmp_le_u32_e64 %[m], %[T], %[s]\n\t"
+                 "v_cmp_eq_u32_e64 %[i], %[init], %[s]\n\t"
+                 "v_alignbit_b32 %[p], %[s], %[p], 8\n\t"
+                 "v_addc_co_u32_e64 %[acc], %[j], %[acc], %[acc], %[m]\n\t"
+                 "v_addc_co_u32_e64 %[ini], %[j], %[ini], %[ini], %[i]\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : [a] "=&v"(a), [t] "=&v"(t), [m] "=&s"(m), [i] "=&s"(i2), [j] "=&s"(junk),
+                   [p] "+v"(packed), [acc] "+v"(accR), [ini] "+v"(iniR)
+                 : [s] "v"(s), [w] "v"(w), [sel] "s"(sel), [T] "s"(T), [init] "s"(init)
+                 : "memory");
+  } else {
+    asm volatile("v_perm_b32 %[a], %[s], %[w], %[sel]\n\t"
+                 "ds_read_u8 %[t], %[a] offset:512\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : [a] "=&v"(a), [t] "=&v"(t)
+                 : [s] "v"(s), [w] "v"(w), [sel] "s"(sel)
+                 : "memory");
+  }
+  s = t;
+}
+
+// the bookkeeping alone, for the state behind the block's last byte
+__device__ __forceinline__ void mabBook(uint32_t s, uint32_t &accR, uint32_t &iniR,
+                                        uint32_t &packed, uint32_t T, uint32_t init) {
+  uint64_t m, i2, junk;
+  asm volatile("v_cmp_le_u32_e64 %[m], %[T], %[s]\n\t"
+               "v_cmp_eq_u32_e64 %[i], %[init], %[s]\n\t"
+               "v_alignbit_b32 %[p], %[s], %[p], 8\n\t"
+               "v_addc_co_u32_e64 %[acc], %[j], %[acc], %[acc], %[m]\n\t"
+               "v_addc_co_u32_e64 %[ini], %[j], %[ini], %[ini], %[i]"
+               : [m] "=&s"(m), [i] "=&s"(i2), [j] "=&s"(junk), [p] "+v"(packed), [acc] "+v"(accR),
+                 [ini] "+v"(iniR)
+               : [s] "v"(s), [T] "s"(T), [init] "s"(init));
+}
+
 // =========================================================================================
 // k_matchall_blocks: matchAllCore (include/Matcher.h:711-766) in two phases per block of a line.
 //
@@ -1763,6 +1815,10 @@ k_matchall_blocks(DevDfa d, Batch b, uint64_t cap, uint64_t *counts, int lead) {
             d.leaderLen};
   uint32_t *stage = reinterpret_cast<uint32_t *>(lds + 512 + ((ldsTableBytes<KIND>(d) + 15) & ~size_t(15)));
   const uint8_t *stageBytes = reinterpret_cast<const uint8_t *>(stage);
+  // the result table's LDS copy, addressed as LDS (through LaneCtx it is a generic pointer: flat loads)
+  const int32_t *ldsRes = reinterpret_cast<const int32_t *>(lds + 512 + ((tableOnlyBytes<KIND>(d) + 15) & ~size_t(15)));
+  // the asm walk addresses the table at LDS offset 512: true while the kernel has no static LDS
+  const bool tableAt512 = uint32_t(reinterpret_cast<uintptr_t>(lds)) == 0u;
   const uint64_t step = uint64_t(gridDim.x) * THREADS;
   for (uint64_t line = uint64_t(blockIdx.x) * THREADS + threadIdx.x; line < b.n; line += step) {
     const uint8_t *p;
@@ -1793,9 +1849,33 @@ k_matchall_blocks(DevDfa d, Batch b, uint64_t cap, uint64_t *counts, int lead) {
 #pragma unroll
       for (uint32_t q = 0; q < kPos / 16; ++q)
         piece[q] = q < nq ? *reinterpret_cast<const uint4 *>(p + base + 16 * q) : make_uint4(0, 0, 0, 0);
+      bool walked = false;
+      if constexpr (KIND == REDGPU_TAB_LDS_FUSED_U8 && W == 1) {
+        if (nq == kPos / 16 && tableAt512) {
+          // a whole block over the fused table: mabStep, masks first-position-high, two halves
+          uint32_t aR[2] = {0, 0}, iR[2] = {0, 0}, packed = 0;
+#pragma unroll
+          for (uint32_t pos = 0; pos < 64; ++pos) {
+            const uint4 &pc = piece[pos >> 4];
+            const uint32_t word = (pos >> 2) % 4 == 0 ? pc.x : (pos >> 2) % 4 == 1 ? pc.y
+                                  : (pos >> 2) % 4 == 2 ? pc.z : pc.w;
+            const uint32_t sel = 0x0c0c0400u + (pos & 3u);
+            // the bookkeeping inside step `pos` is for position pos - 1
+            if (pos == 0) mabStep<false>(s, word, sel, aR[0], iR[0], packed, c.firstAccept, c.init);
+            else mabStep<true>(s, word, sel, aR[(pos - 1) >> 5], iR[(pos - 1) >> 5], packed,
+                               c.firstAccept, c.init);
+            if (pos && pos % 4 == 0) stage[(pos / 4 - 1) * THREADS + threadIdx.x] = packed;
+          }
+          mabBook(s, aR[1], iR[1], packed, c.firstAccept, c.init);
+          stage[15 * THREADS + threadIdx.x] = packed;
+          acc = (uint64_t(__builtin_bitreverse32(aR[1])) << 32) | __builtin_bitreverse32(aR[0]);
+          ini = (uint64_t(__builtin_bitreverse32(iR[1])) << 32) | __builtin_bitreverse32(iR[0]);
+          walked = true;
+        }
+      }
 #pragma unroll
       for (uint32_t q = 0; q < kPos / 16; ++q) {
-        if (q < nq) {
+        if (!walked && q < nq) {
           const uint32_t words[4] = {piece[q].x, piece[q].y, piece[q].z, piece[q].w};
           uint32_t packed = 0;
 #pragma unroll
@@ -1828,32 +1908,47 @@ k_matchall_blocks(DevDfa d, Batch b, uint64_t cap, uint64_t *counts, int lead) {
       // ---- B: the accepting positions ----------------------------------------------------------
       const uint64_t valid = cnt >= 64 ? ~0ull : (1ull << cnt) - 1;
       const uint64_t esc = (((ini << 1) | wasInit) & ~ini) & valid;  // "left the initial state" here
-      uint64_t todo = acc;
       const bool lastAcc = prevR != 0;
-      while (todo) {
-        const uint32_t i = uint32_t(__builtin_ctzll(todo));
-        todo &= todo - 1;
-        const bool contig = i ? ((acc >> (i - 1)) & 1u) != 0 : lastAcc;
+      auto resultAt = [&](uint32_t i) -> int32_t {
         const uint8_t *slot = stageBytes + (((i / kPerWord) * THREADS + threadIdx.x) << 2) +
                               W * (i % kPerWord);
         const uint32_t si = W == 1 ? uint32_t(*slot) : uint32_t(*reinterpret_cast<const uint16_t *>(slot));
-        const int32_t r = c.res[si];
-        if (r != (contig ? prevR : 0)) {
-          if (found && found - 1 < cap && en) en[found - 1] = curEnd;
-          if (found < cap) {
-            res[found] = r;
-            if (st) {
-              const uint64_t m = esc & ((2ull << i) - 1);
-              st[found] = m ? base + 63 - uint32_t(__builtin_clzll(m)) : matchStart;
-            }
-          }
-          ++found;
-        }
-        curEnd = base + i + 1;
-        prevR = r;
+        return ldsRes[si];
+      };
+      // B1. where records OPEN.  An accepting position behind a non-accepting one always does
+      //     (prev is 0 there, :757); one behind an accepting position does when the two results
+      //     differ (:747-752) - only those pairs need their results looked up.
+      const uint64_t behindAcc = (acc << 1) | (lastAcc ? 1u : 0u);
+      uint64_t opens = acc & ~behindAcc;
+      for (uint64_t pairs = acc & behindAcc; pairs; pairs &= pairs - 1) {
+        const uint32_t i = uint32_t(__builtin_ctzll(pairs));
+        const int32_t before = i ? resultAt(i - 1) : prevR;
+        if (resultAt(i) != before) opens |= 1ull << i;
       }
-      // carried into the next block: does its first position continue a run, and the last escape
-      if (!(cnt && ((acc >> (cnt - 1)) & 1u))) prevR = 0;
+      // B2. the records themselves, while there is something to store (record cap - 1 waits for
+      //     its end until the next one opens): the k-th trip stores every lane's k-th record of
+      //     the block - a record ends behind the last accepting position before the next open.
+      while (opens && cap && found <= cap) {
+        const uint32_t i = uint32_t(__builtin_ctzll(opens));
+        opens &= opens - 1;
+        if (found && found - 1 < cap && en) {
+          const uint64_t below = acc & ((1ull << i) - 1);
+          en[found - 1] = below ? base + 64 - uint32_t(__builtin_clzll(below)) : curEnd;
+        }
+        if (found < cap) {
+          res[found] = resultAt(i);
+          if (st) {
+            const uint64_t m = esc & ((2ull << i) - 1);
+            st[found] = m ? base + 63 - uint32_t(__builtin_clzll(m)) : matchStart;
+          }
+        }
+        ++found;
+      }
+      found += uint64_t(__builtin_popcountll(opens));  // the rest is only counted
+      // carried into the next block: the end of the run in progress, whether its first position
+      // continues a run (and with which result), and the last escape from the initial state
+      if (acc) curEnd = base + 64 - uint32_t(__builtin_clzll(acc));
+      prevR = cnt && ((acc >> (cnt - 1)) & 1u) ? resultAt(cnt - 1) : 0;
       if (esc) matchStart = base + 63 - uint32_t(__builtin_clzll(esc));
     }
     if (found && found - 1 < cap && en) en[found - 1] = curEnd;

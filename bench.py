@@ -54,6 +54,9 @@ def parse_args():
     ap.add_argument("--lines", type=int, default=None, help="override the config's line count")
     ap.add_argument("--buffers", type=int, default=None)
     ap.add_argument("--no-start", action="store_true", help="outputs result + end only")
+    ap.add_argument("--rehearse-gather", action="store_true",
+                    help="one GPU: run the N > 1 loop (every step's records packed, gathered over "
+                         "a ONE-rank RCCL group and widened on the root) to price the root's share")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-calibration", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -300,17 +303,25 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
+    rehearse = bool(getattr(args, "rehearse_gather", False)) and world == 1
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
+    elif rehearse:
+        import tempfile
+        import torch.distributed as dist
+        rdv = os.path.join(tempfile.mkdtemp(prefix="bench_rdv_"), "rdv")
+        dist.init_process_group("nccl", init_method="file://" + rdv, rank=0, world_size=1,
+                                device_id=torch.device("cuda", local_rank))
+    multi = world > 1 or rehearse
 
     if args.config is None:
-        args.config = 1 if world == 1 else 2
+        args.config = 2 if multi else 1
     if args.streams is None:
-        args.streams = 3 if (args.config == 1 and world == 1) else 1
+        args.streams = 3 if (args.config == 1 and not multi) else 1
     if args.steps is None:
         args.steps = {1: 300, 2: 20, 3: 40, 4: 5}[args.config]
     if args.warmup is None:
@@ -337,7 +348,7 @@ def main():
 
     # ---- multi-GPU: every step's Outcomes gathered to rank 0 (compact records, pipelined) -------
     gather = None
-    if world > 1:
+    if multi:
         from one_amd import sharding
         max_len = wl.L if not wl.ragged else 256
         gather = sharding.StepGather(n, info["max_result"], max_len, wl.want_start, depth=2,
@@ -350,7 +361,7 @@ def main():
     # rank 0 alone, untimed: the same per-GPU workload on ONE GPU, so that the weak-scaling
     # reference of a multi-GPU line is this workload and not another config
     solo = None
-    if world > 1:
+    if multi:
         if rank == 0:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -588,7 +599,10 @@ def main():
             "sharding": "contiguous shard per GPU, no data-path collective" +
                         ("; EVERY step's Outcomes gathered to rank 0 over %s as compact records "
                          "(pipelined, 2 in flight)" % ("RCCL" if backend == "nccl" else "gloo")
-                         if world > 1 else ""),
+                         if multi else "") +
+                        (" - REHEARSAL on one GPU: a one-rank RCCL group, so the pack / collective "
+                         "call / widen-on-root cost of a step is in the number but no bytes cross "
+                         "xGMI" if rehearse else ""),
         },
         "minputs_per_s": round(world * args.steps * n / elapsed / 1e6, 1),
         "bit_exact": bit_exact,

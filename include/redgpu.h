@@ -374,6 +374,24 @@ int redgpu_group_batch_dev(redgpu_group *group, int verb, int style, int do_lead
                            uint64_t stride, const uint64_t *n, int32_t *result, uint64_t *start,
                            uint64_t *end, int gather, void *root_stream);
 
+/* The compact record format of redgpu_group_batch_dev, for callers that move the results
+ * themselves (one process per GPU over torch.distributed / RCCL: one_amd/sharding.py).  A
+ * shard's n Outcomes become three planes, each starting on a 16-byte boundary:
+ *   [result: n x result_width][start: n x pos_width (absent when start == NULL)][end: n x pos_width]
+ * little-endian, result_width in {1,2,4} (results are >= 0, include/Types.h:22), pos_width in
+ * {1,2,4,8}; the caller picks widths that hold the DFA's largest result and the longest line.
+ *   redgpu_records_bytes       size of a packed shard
+ *   redgpu_records_pack_dev    device arrays -> packed (device) buffer, on `stream`
+ *   redgpu_records_unpack_dev  packed buffer -> int32 result / 64-bit start, end (device), on `stream`
+ * All pointers are memory of `device` (REDGPU_DEVICE_CURRENT = the caller's current device). */
+uint64_t redgpu_records_bytes(uint64_t n, int result_width, int pos_width, int with_start);
+int redgpu_records_pack_dev(int32_t device, const int32_t *result, const uint64_t *start,
+                            const uint64_t *end, uint64_t n, int result_width, int pos_width,
+                            void *records, void *stream);
+int redgpu_records_unpack_dev(int32_t device, const void *records, uint64_t n, int result_width,
+                              int pos_width, int32_t *result, uint64_t *start, uint64_t *end,
+                              void *stream);
+
 /* Name of the kernel the last *_batch* call on this thread launched (for profiles), or "". */
 const char *redgpu_last_kernel(void);
 

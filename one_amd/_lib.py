@@ -157,6 +157,12 @@ def lib() -> C.CDLL:
         l.redgpu_group_batch_dev.restype = C.c_int
         l.redgpu_group_batch_dev.argtypes = [vp, i32, i32, i32, vp, vp, u64, vp, vp, vp, vp, i32,
                                              vp]
+        l.redgpu_records_bytes.restype = u64
+        l.redgpu_records_bytes.argtypes = [u64, i32, i32, i32]
+        l.redgpu_records_pack_dev.restype = C.c_int
+        l.redgpu_records_pack_dev.argtypes = [C.c_int32, vp, vp, vp, u64, i32, i32, vp, vp]
+        l.redgpu_records_unpack_dev.restype = C.c_int
+        l.redgpu_records_unpack_dev.argtypes = [C.c_int32, vp, u64, i32, i32, vp, vp, vp, vp]
         _lib = l
     return _lib
 

@@ -290,6 +290,56 @@ void redgpu_group_destroy(redgpu_group *g) {
 
 uint32_t redgpu_group_size(const redgpu_group *g) { return g ? uint32_t(g->m.size()) : 0; }
 
+// ---- the record format on its own (one process per GPU: one_amd/sharding.py) -----------------
+static bool widthsOk(int rw, int pw) {
+  return (rw == 1 || rw == 2 || rw == 4) && (pw == 1 || pw == 2 || pw == 4 || pw == 8);
+}
+
+uint64_t redgpu_records_bytes(uint64_t n, int rw, int pw, int withStart) {
+  if (!widthsOk(rw, pw)) return 0;
+  return planeBytes(n, rw) + (withStart ? planeBytes(n, pw) : 0) + planeBytes(n, pw);
+}
+
+static int recordsLaunch(int32_t device, bool pack, const void *rec, uint64_t n, int rw, int pw,
+                         const int32_t *res, const uint64_t *start, const uint64_t *end,
+                         void *stream) {
+  if (!widthsOk(rw, pw)) return fail(REDGPU_EAPI, "record widths must be 1/2/4 (result) and 1/2/4/8 (positions)");
+  if (n == 0) return REDGPU_OK;
+  if (!rec || !res || !end) return fail(REDGPU_EAPI, "null records / result / end buffer");
+  int dev = device;
+  if (dev == REDGPU_DEVICE_CURRENT) {
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return failHip(e, "hipGetDevice");
+  }
+  DeviceScope scope(dev);
+  if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  const uint64_t want = (n + 255) / 256;
+  const uint32_t blocks = uint32_t(want < 4096 ? want : 4096);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (pack)
+    hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, st, res, start, end, n, rw, pw,
+                       static_cast<uint8_t *>(const_cast<void *>(rec)));
+  else
+    hipLaunchKernelGGL(k_unpack, dim3(blocks), dim3(256), 0, st, static_cast<const uint8_t *>(rec),
+                       n, rw, pw, const_cast<int32_t *>(res), const_cast<uint64_t *>(start),
+                       const_cast<uint64_t *>(end));
+  hipError_t e = hipGetLastError();
+  tlsKernel = pack ? "k_pack" : "k_unpack";
+  if (e != hipSuccess) return failHip(e, "kernel launch");
+  return REDGPU_OK;
+}
+
+int redgpu_records_pack_dev(int32_t device, const int32_t *result, const uint64_t *start,
+                            const uint64_t *end, uint64_t n, int rw, int pw, void *records,
+                            void *stream) {
+  return recordsLaunch(device, true, records, n, rw, pw, result, start, end, stream);
+}
+
+int redgpu_records_unpack_dev(int32_t device, const void *records, uint64_t n, int rw, int pw,
+                              int32_t *result, uint64_t *start, uint64_t *end, void *stream) {
+  return recordsLaunch(device, false, records, n, rw, pw, result, start, end, stream);
+}
+
 const redgpu_dfa *redgpu_group_member(const redgpu_group *g, uint32_t i) {
   return g && i < g->m.size() ? g->m[i].dfa : nullptr;
 }

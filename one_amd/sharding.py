@@ -114,15 +114,19 @@ def gather_outcomes(result, start, end, *, max_result: int, max_line_len: int, d
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     fmt = RecordFormat(max_result, max_line_len, with_start=start is not None)
-    rec = fmt.pack(result, start, end)
+    n_here = int(result.numel())
     if equal_counts:
-        counts = [rec.shape[0]] * world
+        counts = [n_here] * world
     else:
-        n_local = torch.tensor([rec.shape[0]], dtype=torch.int64, device=rec.device)
+        n_local = torch.tensor([n_here], dtype=torch.int64, device=result.device)
         counts = [torch.zeros_like(n_local) for _ in range(world)]
         dist.all_gather(counts, n_local, group=group)
         counts = [int(c.item()) for c in counts]
     n_max = max(counts) if counts else 0
+    if result.is_cuda:
+        return _gather_native(result, start, end, fmt, counts, n_max, rank, world, dst, group,
+                              async_op)
+    rec = fmt.pack(result, start, end)
     # equal-size gather (one collective, every link busy at once); pad the short shards
     padded = rec
     if rec.shape[0] < n_max:
@@ -149,6 +153,60 @@ def gather_outcomes(result, start, end, *, max_result: int, max_line_len: int, d
         st = torch.cat([p[1] for p in parts]) if fmt.with_start else None
         en = torch.cat([p[2] for p in parts])
         return res, st, en
+
+    return finish
+
+
+def _gather_native(result, start, end, fmt, counts, n_max, rank, world, dst, group, async_op):
+    """Device tensors: the records are packed and widened by the library's own kernels
+    (redgpu_records_pack_dev / _unpack_dev, include/redgpu.h) - one launch per shard instead of
+    a dozen elementwise torch kernels per field, which is what the root's GPU would otherwise
+    spend a fifth of a step on.  Wire format: the plane layout of redgpu_records_bytes; every
+    rank packs with its own line count, the root unpacks shard r with counts[r]."""
+    import ctypes as C
+    from . import _lib
+    l = _lib.lib()
+    dev = result.device
+    with_start = start is not None
+    nbytes = int(l.redgpu_records_bytes(n_max, fmt.rw, fmt.pw, int(with_start)))
+    rec = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    res32 = result.to(torch.int32).contiguous()
+    st64 = start.to(torch.int64).contiguous() if with_start else None
+    en64 = end.to(torch.int64).contiguous()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def check(rc):
+        if rc != 0:
+            raise RuntimeError(l.redgpu_last_error().decode())
+
+    check(l.redgpu_records_pack_dev(dev.index, res32.data_ptr(),
+                                    st64.data_ptr() if with_start else None, en64.data_ptr(),
+                                    res32.numel(), fmt.rw, fmt.pw, rec.data_ptr(), C.c_void_p(stream)))
+    bufs = whole = None
+    if rank == dst:
+        whole = torch.empty((world, rec.numel()), dtype=torch.uint8, device=dev)
+        bufs = list(whole.unbind(0))
+    work = dist.gather(rec, gather_list=bufs, dst=dst, group=group, async_op=async_op)
+
+    def finish():
+        if async_op and work is not None:
+            work.wait()
+        if rank != dst:
+            return None
+        total = sum(counts)
+        out_r = torch.empty(total, dtype=torch.int32, device=dev)
+        out_s = torch.empty(total, dtype=torch.int64, device=dev) if with_start else None
+        out_e = torch.empty(total, dtype=torch.int64, device=dev)
+        s2 = torch.cuda.current_stream(dev).cuda_stream
+        at = 0
+        for r in range(world):
+            if counts[r]:
+                check(l.redgpu_records_unpack_dev(
+                    dev.index, bufs[r].data_ptr(), counts[r], fmt.rw, fmt.pw,
+                    out_r.data_ptr() + 4 * at, (out_s.data_ptr() + 8 * at) if with_start else None,
+                    out_e.data_ptr() + 8 * at, C.c_void_p(s2)))
+            at += counts[r]
+        return out_r, out_s, out_e
 
     return finish
 

@@ -206,3 +206,77 @@ def test_group_device_shards_gathered_on_root(ndev, gather):
     exp = [cpu.batch("match", 4, 0, d, offsets=o, threads=4) for d, o in parts]
     cat = [np.concatenate([x[k] for x in exp]) for k in range(3)]
     assert _eq((r.cpu().numpy(), s.cpu().numpy(), e.cpu().numpy()), cat)
+
+
+@pytest.mark.parametrize("rw,pw,with_start", [(1, 1, True), (1, 2, True), (2, 4, False),
+                                              (4, 8, True)])
+def test_record_planes_pack_and_unpack_roundtrip(rw, pw, with_start):
+    """redgpu_records_pack_dev / _unpack_dev: the compact record planes on their own (what one
+    process per GPU sends over RCCL), every width, odd counts (planes start 16-byte aligned)."""
+    import ctypes as C
+    import torch
+    l = _lib.lib()
+    rng = np.random.default_rng(rw * 10 + pw)
+    for n in (1, 63, 4097, 100003):
+        res = rng.integers(0, min(2 ** (8 * rw), 2 ** 31), n, dtype=np.int64).astype(np.int32)
+        hi = 2 ** (8 * pw) if pw < 8 else 2 ** 63
+        st = rng.integers(0, hi, n, dtype=np.uint64 if pw == 8 else np.int64).astype(np.int64)
+        en = rng.integers(0, hi, n, dtype=np.uint64 if pw == 8 else np.int64).astype(np.int64)
+        d_res, d_st, d_en = (torch.from_numpy(x).cuda() for x in (res, st, en))
+        nbytes = l.redgpu_records_bytes(n, rw, pw, int(with_start))
+        assert nbytes >= n * (rw + pw * (2 if with_start else 1)) and nbytes % 16 == 0
+        rec = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        assert l.redgpu_records_pack_dev(0, d_res.data_ptr(), d_st.data_ptr() if with_start else None,
+                                         d_en.data_ptr(), n, rw, pw, rec.data_ptr(), stream) == 0
+        o_res = torch.empty(n, dtype=torch.int32, device="cuda")
+        o_st = torch.empty(n, dtype=torch.int64, device="cuda")
+        o_en = torch.empty(n, dtype=torch.int64, device="cuda")
+        assert l.redgpu_records_unpack_dev(0, rec.data_ptr(), n, rw, pw, o_res.data_ptr(),
+                                           o_st.data_ptr() if with_start else None,
+                                           o_en.data_ptr(), stream) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(o_res.cpu().numpy(), res)
+        assert np.array_equal(o_en.cpu().numpy(), en)
+        if with_start:
+            assert np.array_equal(o_st.cpu().numpy(), st)
+        # the plane layout itself: results first, little-endian
+        assert np.array_equal(rec[: n * rw].cpu().numpy().view({1: np.uint8, 2: np.uint16, 4: np.uint32}[rw]),
+                              res.astype({1: np.uint8, 2: np.uint16, 4: np.uint32}[rw]))
+    assert l.redgpu_records_pack_dev(0, None, None, None, 5, 3, 2, None, None) == _lib.EAPI
+
+
+def test_gather_outcomes_native_records_over_rccl_one_rank(tmp_path):
+    """one_amd.sharding.gather_outcomes on DEVICE tensors (the bench's N > 1 path): records
+    packed and widened by the library's kernels, moved by torch.distributed's nccl (= RCCL)
+    backend - one rank here; the two-rank form of the same function runs over gloo on the CPU."""
+    import torch
+    import torch.distributed as dist
+    from one_amd import sharding
+    dist.init_process_group("nccl", init_method="file://%s" % (tmp_path / "rdv"), rank=0,
+                            world_size=1)
+    try:
+        blob = load_dfa("uri")
+        cpu = O.CpuOracle(blob)
+        exe = one_amd.Executable(blob)
+        host = W.fixed_lines(5000, 4096, 9, alphabet=True, plant=W.URI_PLANT)
+        data = torch.from_numpy(host).cuda()
+        r, s, e = one_amd.match_batch(exe, data, 4, 0, stride=4096, n=5000)  # device tensors
+        assert r.is_cuda and s.dtype == torch.int64
+        exp = cpu.batch("match", 4, 0, host, stride=4096, n=5000, threads=4)
+        for eq in (True, False):
+            for with_start in (True, False):
+                fin = sharding.gather_outcomes(r, s if with_start else None, e,
+                                               max_result=exe.info["max_result"], max_line_len=4096,
+                                               equal_counts=eq, async_op=True)
+                gr, gs, ge = fin()
+                torch.cuda.synchronize()
+                assert gr.dtype == torch.int32 and ge.dtype == torch.int64
+                assert np.array_equal(gr.cpu().numpy(), exp[0])
+                assert np.array_equal(ge.cpu().numpy().astype(np.uint64), exp[2].astype(np.uint64))
+                if with_start:
+                    assert np.array_equal(gs.cpu().numpy().astype(np.uint64), exp[1].astype(np.uint64))
+                else:
+                    assert gs is None
+    finally:
+        dist.destroy_process_group()

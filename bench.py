@@ -515,6 +515,23 @@ def main():
                                                 "launch (not the workload: shows the launch's head + tail)" %
                                                 (big_n, wl.L))
             del big, br, bs, be
+        # (c3) the north star's literal outputs - result code and end offset, no start: the same
+        # batch through the same entry point with start = NULL (12 B written per line, not 20)
+        if wl.want_start and not wl.ragged and args.config in (1, 2):
+            t = list(wl.call_tuple(0, cur_stream))
+            t[8] = None
+            reps = 20 if args.config == 1 else 5
+            for _ in range(2):
+                fn(*t)
+            c0.record()
+            for _ in range(reps):
+                fn(*t)
+            c1.record()
+            torch.cuda.synchronize()
+            calib["result_end_only_GBps"] = round(reps * wl.in_bytes / (c0.elapsed_time(c1) * 1e-3) / 1e9, 1)
+            calib["result_end_only_how"] = ("the same batch and entry point with start = NULL (result + end, "
+                                            "the outputs north_star names), %d launches back to back on one "
+                                            "stream; `value` keeps the full Outcome" % reps)
         # (d) bytes the walk actually reads (early-exit DFAs)
         if info["early_death"] or wl.ragged:
             w = torch.zeros(1, dtype=torch.int64, device="cuda")

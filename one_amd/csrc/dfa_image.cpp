@@ -208,6 +208,41 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
       }, img.start2FreeWord, img.start2FreeCount);
   }
 
+  // ... and the full flag tables
+  {
+    std::vector<uint32_t> firsts;
+    bool firstAccepts = false;
+    for (uint32_t c = 0; c < nCls; ++c) {
+      uint32_t t = 0;
+      targetOf(rawInit, c, t);
+      if (klass(t) == 0) continue;
+      if (klass(t) == 2) firstAccepts = true;
+      firsts.push_back(t);
+    }
+    img.startTotal[0] = img.startTotal[1] = 0;
+    img.startFollow[0] = !firstAccepts;
+    img.startFollow[1] = leaderLen > 1;
+    for (uint32_t b = 0; b < 256; ++b) {
+      const uint8_t cls = h[kOffEquivMap + b];
+      uint32_t t = 0;
+      targetOf(rawInit, cls, t);
+      uint8_t f0 = klass(t) != 0 ? 1 : 0;
+      if (img.startFollow[0])
+        for (uint32_t f1 : firsts) {
+          uint32_t t2 = 0;
+          targetOf(f1, cls, t2);
+          if (klass(t2) != 0) { f0 |= 2; break; }
+        }
+      img.startFlags[0][b] = f0;
+      img.startTotal[0] += f0 & 1u;
+      uint8_t fl = 0;
+      if (leaderLen > 0 && cls == h[kHeaderBytes]) fl |= 1;
+      if (leaderLen > 1 && cls == h[kHeaderBytes + 1]) fl |= 2;
+      img.startFlags[1][b] = fl;
+      img.startTotal[1] += fl & 1u;
+    }
+  }
+
   // table placement (decided before the renumbering: the hot-row kind orders states its own way)
   if (ldsTableMax == 0)
     ldsTableMax = 144u * 1024u;

@@ -51,6 +51,12 @@ struct DfaImage {
   // byte accepts at once).  Same packing; 0xff = no second filter.
   uint32_t start2LeadWord = 0, start2LeadCount = 0xff;
   uint32_t start2FreeWord = 0, start2FreeCount = 0xff;
+  // The same two sets in full, one flag byte per input byte ([0] without the leader, [1] with
+  // it): bit 0 = start byte, bit 1 = may follow one.  For DFAs with more than 4 start bytes
+  // (a pattern that begins with a character class) k_scan_marked tests bytes against this table.
+  uint8_t  startFlags[2][256] = {};
+  uint32_t startTotal[2] = {256, 256};   // how many byte values are start bytes
+  bool     startFollow[2] = {false, false};  // bit 1 is meaningful (else: anything may follow)
   std::vector<int32_t>  result;   // [nStates]
   std::vector<uint32_t> next;     // [nStates][nClasses], device indices
   std::vector<uint32_t> rawOf;    // [nStates] device index -> state id in the blob

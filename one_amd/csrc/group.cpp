@@ -534,6 +534,10 @@ int redgpu_group_batch_dev(redgpu_group *g, int verb, int style, int do_leader,
   }
   if (useRccl) {
     Rccl &r = rccl();
+    if (g->consumedValid && !n[0]) {  // an empty root shard skipped the wait above; its stream receives
+      DeviceScope scope(rootDev);
+      HIP_TRY(hipStreamWaitEvent(g->m[0].stream, g->consumed, 0), "hipStreamWaitEvent");
+    }
     int rc = r.GroupStart();
     if (rc != 0) return failRccl(rc, "ncclGroupStart");
     for (size_t k = 1; k < G && rc == 0; ++k) {

@@ -39,6 +39,9 @@ struct DevDfa {
   // start bytes for scan / search (dfa_image.h): packed members, count (0xff = no filter)
   uint32_t startLeadWord, startLeadCount, startFreeWord, startFreeCount;
   uint32_t start2LeadWord, start2LeadCount, start2FreeWord, start2FreeCount;
+  // full start / follow flag tables behind equivLeader: [512..768) without the leader,
+  // [768..1024) with it (DfaImage::startFlags); how many start bytes; whether bit 1 means anything
+  uint32_t startTotal[2], startFollow[2];
 };
 
 // One batch of lines (device pointers).

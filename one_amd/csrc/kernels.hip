@@ -1119,6 +1119,15 @@ k_early(DevDfa d, Batch b, int style, int lead) {
 constexpr uint32_t kMarkBytes = 8192;
 constexpr int kScanThreads = 256;
 
+// scan / search through k_scan_marked: the DFA's start bytes are few - up to 4 as a packed list
+// tested a word at a time, up to 64 (a leading character class) through the flag table
+inline bool scanMarkable(const DevDfa &d, int lead) {
+  const uint32_t listed = lead ? d.startLeadCount : d.startFreeCount;
+  if (listed >= 1 && listed <= 4) return true;
+  const uint32_t total = d.startTotal[lead ? 1 : 0];
+  return listed > 4 && total >= 1 && total <= 64;
+}
+
 // one bit per byte of `word` that can start a surviving attempt: walkBytesPeek's test - a start
 // byte, followed (n2 != 0) by a byte that may follow one or, with the leader, by another start
 // byte (StartFilter::consumes)
@@ -1131,6 +1140,21 @@ __device__ __forceinline__ uint32_t markNibble(uint32_t word, uint32_t nextWord,
     m &= ok;
   }
   return ((m >> 7) & 1u) | ((m >> 14) & 2u) | ((m >> 21) & 4u) | ((m >> 28) & 8u);
+}
+
+// the same test against the full flag table (DfaImage::startFlags, 256 bytes in LDS): any number
+// of start bytes - a pattern that begins with a character class.  bit 0 = start byte, bit 1 =
+// may follow one; useFollow = the follower is in hand and the second filter means something.
+__device__ __forceinline__ uint32_t markNibbleTbl(uint32_t word, uint32_t nextWord, const uint8_t *tbl,
+                                                  bool useFollow, bool consumes) {
+  const uint32_t f0 = tbl[word & 0xffu], f1 = tbl[(word >> 8) & 0xffu], f2 = tbl[(word >> 16) & 0xffu],
+                 f3 = tbl[word >> 24], f4 = tbl[nextWord & 0xffu];
+  const uint32_t starts = (f0 & 1u) | ((f1 & 1u) << 1) | ((f2 & 1u) << 2) | ((f3 & 1u) << 3);
+  if (!useFollow) return starts;
+  const uint32_t pass = consumes ? 3u : 2u;  // with the leader a start byte may follow too
+  const uint32_t ok = ((f1 & pass) ? 1u : 0u) | ((f2 & pass) ? 2u : 0u) | ((f3 & pass) ? 4u : 0u) |
+                      ((f4 & pass) ? 8u : 0u);
+  return starts & ok;
 }
 
 template <int KIND, int kThreads, int VERB>
@@ -1152,6 +1176,16 @@ k_scan_marked(DevDfa d, Batch b, int style, int lead) {
   uint32_t *candK = reinterpret_cast<uint32_t *>(lineOff + kThreads);  // scan with the leader
   uint32_t *lineFirst = candK + kThreads;   // where a line's candidates start in the list
   uint32_t *waveTot = lineFirst + kThreads;  // candidates per wave (block-wide prefix sum)
+  // more than 4 start bytes: the full flag table instead of the packed list (stageTab's barrier
+  // is behind us; the first use is behind the next one)
+  uint8_t *flagTbl = reinterpret_cast<uint8_t *>(waveTot + 8);
+  const bool useTbl = (lead ? d.startLeadCount : d.startFreeCount) > 4;
+  if (useTbl)
+    for (uint32_t i = threadIdx.x; i < 64; i += kThreads)
+      reinterpret_cast<uint32_t *>(flagTbl)[i] =
+          reinterpret_cast<const uint32_t *>(d.equivLeader + (lead ? 768 : 512))[i];
+  const bool tblFollow = d.startFollow[lead ? 1 : 0] != 0;
+  if (useTbl) __syncthreads();
   LaneCtx c{eq, leader, resOf<KIND>(d, lds), d.init, d.leaderNext, d.nPureDead, d.firstAccept,
             d.leaderLen};
   // The batch's candidates are SPREAD over the threads, one each, instead of every lane visiting
@@ -1211,6 +1245,14 @@ k_scan_marked(DevDfa d, Batch b, int style, int lead) {
         for (int j = 0; j < 4; ++j) {
           const uint64_t k = k0 + uint64_t(j) * kThreads;
           if (k >= pieces) break;
+          if (useTbl) {
+            marks16[k] = uint16_t(markNibbleTbl(v[j].x, v[j].y, flagTbl, tblFollow, flt.consumes) |
+                                  (markNibbleTbl(v[j].y, v[j].z, flagTbl, tblFollow, flt.consumes) << 4) |
+                                  (markNibbleTbl(v[j].z, v[j].w, flagTbl, tblFollow, flt.consumes) << 8) |
+                                  (markNibbleTbl(v[j].w, after[j], flagTbl, tblFollow && k + 1 < pieces,
+                                                 flt.consumes) << 12));
+            continue;
+          }
           StartFilter f = flt;
           if (k + 1 >= pieces) f.n2 = 0;
           marks16[k] = uint16_t(markNibble(v[j].x, v[j].y, flt) | (markNibble(v[j].y, v[j].z, flt) << 4) |
@@ -2404,11 +2446,10 @@ hipError_t launchGeneric(const DevDfa &d, const Batch &b, int verb, int style, i
                        ldsBytes, stream, d, pb, style, lead);                                \
   } while (0)
   // scan / search over a DFA with at most 4 start bytes: mark the candidates, visit only those
-  const uint32_t scanStarts = lead ? d.startLeadCount : d.startFreeCount;
-  if ((verb == kScan || verb == kSearch) && scanStarts >= 1 && scanStarts <= 4 && !cfg.forceGeneric) {
-    // table, bitmap, candidate list + per-line slots (k_scan_marked's spread form)
+  if ((verb == kScan || verb == kSearch) && scanMarkable(d, lead) && !cfg.forceGeneric) {
+    // table, bitmap, candidate list + per-line slots (k_scan_marked's spread form), flag table
     const size_t markLds = 512 + ((ldsTableBytes<KIND>(d) + 15) & ~size_t(15)) + kMarkBytes +
-                           size_t(kScanThreads) * (6 * 4 + 8) + 32;
+                           size_t(kScanThreads) * (6 * 4 + 8) + 32 + 256;
     if (markLds <= 158 * 1024) {
       hipError_t e_ = verb == kScan ? setLds(k_scan_marked<KIND, kScanThreads, kScan>, markLds)
                                     : setLds(k_scan_marked<KIND, kScanThreads, kSearch>, markLds);
@@ -3120,8 +3161,7 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
   }
 
   {
-    const uint32_t scanStarts = lead ? d.startLeadCount : d.startFreeCount;
-    *kernelName = (verb == kScan || verb == kSearch) && scanStarts >= 1 && scanStarts <= 4 &&
+    *kernelName = (verb == kScan || verb == kSearch) && scanMarkable(d, lead) &&
                           !cfg.forceGeneric
                       ? "k_scan_marked" : "k_generic";
   }

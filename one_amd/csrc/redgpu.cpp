@@ -277,15 +277,17 @@ int collectDev(const redgpu_dfa *dfa, int listVerb, const uint8_t *data, const u
 // Uploads im->img to im->device.  Caller holds the device scope.
 int uploadImage(SharedImage *im) {
   const DfaImage &img = im->img;
-  uint8_t eqLead[512];
+  uint8_t eqLead[1024];
   std::memcpy(eqLead, img.equiv, 256);
   std::memcpy(eqLead + 256, img.leader, 256);
+  std::memcpy(eqLead + 512, img.startFlags[0], 256);
+  std::memcpy(eqLead + 768, img.startFlags[1], 256);
   const size_t tabBytes = (img.table.size() + 15) & ~size_t(15);
   hipError_t e;
   if ((e = hipMalloc(&im->dTable, tabBytes + 16)) != hipSuccess) return failHip(e, "hipMalloc table");
   if ((e = hipMalloc(&im->dResult, img.nStates * sizeof(int32_t) + 16)) != hipSuccess)
     return failHip(e, "hipMalloc result");
-  if ((e = hipMalloc(&im->dEquivLeader, 512 + 64)) != hipSuccess) return failHip(e, "hipMalloc equiv");
+  if ((e = hipMalloc(&im->dEquivLeader, 1024 + 64)) != hipSuccess) return failHip(e, "hipMalloc equiv");
   if ((e = hipMemset(im->dTable, 0, tabBytes + 16)) != hipSuccess) return failHip(e, "hipMemset");
   if ((e = hipMemcpy(im->dTable, img.table.data(), img.table.size(), hipMemcpyHostToDevice)) !=
       hipSuccess)
@@ -293,7 +295,7 @@ int uploadImage(SharedImage *im) {
   if ((e = hipMemcpy(im->dResult, img.result.data(), img.nStates * sizeof(int32_t),
                      hipMemcpyHostToDevice)) != hipSuccess)
     return failHip(e, "upload result");
-  if ((e = hipMemcpy(im->dEquivLeader, eqLead, 512, hipMemcpyHostToDevice)) != hipSuccess)
+  if ((e = hipMemcpy(im->dEquivLeader, eqLead, 1024, hipMemcpyHostToDevice)) != hipSuccess)
     return failHip(e, "upload equiv");
 
   DevDfa &d = im->dev;
@@ -336,6 +338,10 @@ int uploadImage(SharedImage *im) {
   d.start2LeadCount = img.start2LeadCount;
   d.start2FreeWord = img.start2FreeWord;
   d.start2FreeCount = img.start2FreeCount;
+  for (int k = 0; k < 2; ++k) {
+    d.startTotal[k] = img.startTotal[k];
+    d.startFollow[k] = img.startFollow[k] ? 1u : 0u;
+  }
   return REDGPU_OK;
 }
 

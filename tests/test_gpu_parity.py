@@ -310,9 +310,10 @@ def test_hot_row_tables_vs_oracle(rows):
             assert np.array_equal(e, vec[key + "end"])
 
 
-@pytest.mark.parametrize("name", ["err", "aab"])  # anchored: scan stays linear on the long line
+@pytest.mark.parametrize("name", ["err", "aab", "num3"])  # anchored: scan stays linear on the long line
 def test_marked_scan_and_search_vs_oracle(name):
-    """k_scan_marked (scan / search, DFAs with <= 4 start bytes): batches that must be halved to
+    """k_scan_marked (scan / search; DFAs with <= 4 start bytes through the packed list, num3 -
+    ten start bytes, a leading character class - through the flag table): batches that must be halved to
     fit the bitmap, a line longer than the bitmap covers (scanned the old way), empty lines,
     candidates on the first / last byte of a line and straddling the 16-byte pieces, fixed
     strides; every style, with and without the leader; against the oracle and against the
@@ -320,7 +321,8 @@ def test_marked_scan_and_search_vs_oracle(name):
     blob = load_dfa(name)
     exe, gen, cpu = one_amd.Executable(blob), one_amd.Executable(blob, force_generic=True), O.CpuOracle(blob)
     rng = np.random.default_rng(5)
-    plants = [b"error", b"aab", b"New York", b"eerror", b"aaab", b"erro", b"e", b"a"]
+    plants = [b"error", b"aab", b"New York", b"eerror", b"aaab", b"erro", b"e", b"a", b"123abcd",
+              b"0", b"4567 ", b"99x"]
     def text(total, seed):
         d = W.alphabet_bytes(max(total, 1), seed)[:total].copy()
         for k in range(0, max(total - 12, 0), 53):

@@ -570,6 +570,10 @@ def main():
                          "~1.5 us dependent-launch gap)" % nk,
         "timed_region_ms_per_step": round(region_ms / args.steps, 5),
     }
+    # "also report total-traffic GB/s = sum(L + out [+ 8]) / t" - what the launch must
+    # move at the least: the lines, their offsets (ragged) and the Outcome fields it writes
+    roofline["total_traffic_GBps"] = round((wl.in_bytes + wl.out_bytes) / (kernel_ms * 1e-3) / 1e9, 1)
+    roofline["total_traffic_frac"] = round(roofline["total_traffic_GBps"] / HBM_PEAK_GBS, 4)
     if traffic_src:
         roofline["traffic_source"] = traffic_src
     if l2_bound:

@@ -58,6 +58,9 @@ def parse_args():
                     help="one GPU: run the N > 1 loop (every step's records packed, gathered over "
                          "a ONE-rank RCCL group and widened on the root) to price the root's share")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tune", action="store_true",
+                    help="hot-row DFAs: keep the static choice of LDS-resident rows (default: "
+                         "redgpu_dfa_tune on a 4 MiB sample of the input, outside the timed region)")
     ap.add_argument("--no-calibration", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--streams", type=int, default=None,
@@ -107,6 +110,14 @@ class Workload:
             self.nbuf = args.buffers or 2
             self.label = "configs[4]"
         self._build_inputs()
+        self.tuned = None
+        if not args.no_tune and self.info["table_kind"] == 6 and not self.ragged:
+            # REDGPU_TAB_HOT_ROWS: re-rank the LDS-resident rows by a sample of the input (outside
+            # the timed region, like the upload; redgpu_dfa_tune)
+            sample_lines = max(1, min(self.n, (4 << 20) // self.L))
+            self.info = self.exe.tune(self.bufs[0][: sample_lines * self.L], stride=self.L,
+                                      n=sample_lines)
+            self.tuned = "hot rows re-ranked on the first %d lines of buffer 0" % sample_lines
 
     # -- inputs ----------------------------------------------------------------------------
     def _build_inputs(self):
@@ -612,6 +623,7 @@ def main():
             "input": "text (47-character alphabet, planted matches)" if wl.text else "uniformly random bytes",
             "lines_per_gpu": n, "line_len": wl.L if not wl.ragged else "32..256",
             "rotating_input_buffers": len(wl.bufs),
+            "hot_rows": wl.tuned or ("static choice" if info["table_kind"] == 6 else None),
             "working_set_bytes": len(wl.bufs) * wl.in_bytes,
             "streams": args.streams,
             "value_is": ("steps issued round-robin on %d HIP streams: up to %d independent batches in "

@@ -205,13 +205,13 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
 // block re-walk the block's `rem` valid bytes from its saved entry state - hot steps through the
 // LDS table, cold ones through the class table - with the bookkeeping in global state ids.
 template <int MODE>
-__device__ __noinline__ SlowBook slowRagged(const DevDfa &d, const uint8_t *tab8, const uint8_t *p,
-                                            uint32_t off, uint32_t rem, SlowBook in) {
+__device__ __noinline__ SlowBook slowRagged(const DevDfa &d, const uint8_t *tab8, const uint8_t *eq,
+                                            const uint8_t *p, uint32_t off, uint32_t rem,
+                                            SlowBook in) {
   uint32_t st = in.st, accS = in.accS, endv = in.endv, startv = in.startv;
   constexpr bool kAcc = MODE == kSmLastStartEnd || MODE == kSmLastEnd;
   constexpr bool kStart = MODE == kSmLastStartEnd || MODE == kSmFullStart;
   const uint16_t *cls = reinterpret_cast<const uint16_t *>(d.table);
-  const uint8_t *eq = d.equivLeader;
   // four 16-byte requests (the whole block is readable: k_ragged read it from here), then
   // `rem` steps
 #pragma unroll 1
@@ -310,7 +310,11 @@ k_ragged(DevDfa d, Batch io) {
       const uint32_t i = k * THREADS + threadIdx.x;
       if (!BIG && i < (kStreamTabBytes + 1024) / 16) dst[i] = v[k];
     }
-    if (!CLS && threadIdx.x < 256) ldsRes[threadIdx.x] = myRes;
+    if (!CLS && threadIdx.x < 256) {
+      // HOT: the kilobyte holds the byte -> class map for slowRagged()'s cold steps (k_stream.h)
+      if (TABK == kTabHot) reinterpret_cast<uint8_t *>(ldsRes)[threadIdx.x] = d.equivLeader[threadIdx.x];
+      else ldsRes[threadIdx.x] = myRes;
+    }
     if (threadIdx.x == 0) cursor = 0;
   }
   asm volatile("" : : "v"(tab) : "memory");  // the table is read from inline asm: see k_stream.h
@@ -486,7 +490,8 @@ k_ragged(DevDfa d, Batch io) {
       for (int c = 0; c < CH; ++c) {
         if (redo[c]) {
           const SlowBook o = slowRagged<MODE>(
-              d, tab, blockPtr(lineOff[c] + done[c]), done[c], rem[c],
+              d, tab, reinterpret_cast<const uint8_t *>(ldsRes), blockPtr(lineOff[c] + done[c]),
+              done[c], rem[c],
               SlowBook{g[c] != kNoState ? g[c] : toGlobal(s0[c]), accS[c], endv[c], startv[c]});
           accS[c] = o.accS; endv[c] = o.endv; startv[c] = o.startv;
           s[c] = toHot(o.st);

@@ -288,13 +288,14 @@ struct SlowBook {  // by value in and out: nothing of the fast path has its addr
 };
 
 template <int MODE>
-__device__ __noinline__ SlowBook slowHalf(const DevDfa &d, const uint8_t *tab8, const uint8_t *p,
-                                          uint32_t off, SlowBook in) {
+__device__ __noinline__ SlowBook slowHalf(const DevDfa &d, const uint8_t *tab8, const uint8_t *eq,
+                                          const uint8_t *p, uint32_t off, SlowBook in) {
   uint32_t st = in.st, accS = in.accS, endv = in.endv, startv = in.startv;
   constexpr bool kAcc = (MODE == kSmLastStartEnd || MODE == kSmChunk) || MODE == kSmLastEnd;
   constexpr bool kStart = (MODE == kSmLastStartEnd || MODE == kSmChunk) || MODE == kSmFullStart;
   const uint16_t *cls = reinterpret_cast<const uint16_t *>(d.table);
-  const uint8_t *eq = d.equivLeader;
+  // (eq: the class map's LDS copy - read from global memory a cold step was two dependent
+  // round trips, the class and then the row)
   // the block comes back in four 16-byte requests (it is still in L1/L2), not 64 byte loads:
   // the lanes waiting on this one pay for every round trip
 #pragma unroll 1
@@ -437,7 +438,12 @@ k_stream(DevDfa d, Batch io) {
       // (the result words behind a fused / hot table are written below, by other threads)
       if (!BIG && i < (kStreamTabBytes + (CLS ? 1024 : 0)) / 16) dst[i] = tv[k];
     }
-    if (!CLS && threadIdx.x < 256) ldsRes[threadIdx.x] = myRes;
+    if (!CLS && threadIdx.x < 256) {
+      // HOT keeps no results in LDS (its state values are hot indices): the kilobyte holds the
+      // byte -> class map instead, for the cold steps of slowHalf()
+      if (HOT) reinterpret_cast<uint8_t *>(ldsRes)[threadIdx.x] = d.equivLeader[threadIdx.x];
+      else ldsRes[threadIdx.x] = myRes;
+    }
   }
   // The byte steps read this table from inline asm only.  Unless its address visibly reaches an
   // asm statement the compiler may treat the array as never read and drop the stores above -
@@ -517,7 +523,8 @@ k_stream(DevDfa d, Batch io) {
             uint32_t st = g[c] != kNoState ? g[c] : toGlobal(s0[c]);
             // lanes past the end of the batch walked a clamped line: nothing of theirs is kept
             if (ln < io.n) {
-              const SlowBook o = slowHalf<MODE>(d, tab, io.data + ln * lineLen + off, off,
+              const SlowBook o = slowHalf<MODE>(d, tab, reinterpret_cast<const uint8_t *>(ldsRes),
+                                                io.data + ln * lineLen + off, off,
                                                 SlowBook{st, accS[c], endv[c], startv[c]});
               st = o.st; accS[c] = o.accS; endv[c] = o.endv; startv[c] = o.startv;
             }

@@ -114,10 +114,11 @@ class Workload:
         if not args.no_tune and self.info["table_kind"] == 6 and not self.ragged:
             # REDGPU_TAB_HOT_ROWS: re-rank the LDS-resident rows by a sample of the input (outside
             # the timed region, like the upload; redgpu_dfa_tune)
-            sample_lines = max(1, min(self.n, (4 << 20) // self.L))
-            self.info = self.exe.tune(self.bufs[0][: sample_lines * self.L], stride=self.L,
-                                      n=sample_lines)
-            self.tuned = "hot rows re-ranked on the first %d lines of buffer 0" % sample_lines
+            # (the sample is walked as 1 KiB pieces: the visit histogram wants lanes, not whole lines)
+            sample = min(self.n * self.L, 4 << 20)
+            piece = min(self.L, 1024)
+            self.info = self.exe.tune(self.bufs[0][:sample], stride=piece, n=sample // piece)
+            self.tuned = "hot rows re-ranked on the first %d bytes of buffer 0" % sample
 
     # -- inputs ----------------------------------------------------------------------------
     def _build_inputs(self):

@@ -21,7 +21,8 @@ import sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-SKIP = ("k_diag", "rocclr", "at::", "k_walked", "elementwise", "distribution", "k_pack", "k_unpack")
+SKIP = ("k_diag", "rocclr", "at::", "k_walked", "elementwise", "distribution", "k_pack", "k_unpack",
+        "k_visits")
 
 
 def newest(pattern):

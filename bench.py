@@ -439,6 +439,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         bit_exact = bool(t.item())
 
+    # ---- what the root gathered for the LAST step = every rank's own last output ---------------
+    # (a checksum of checksums: each rank sums its result / start / end arrays, the root sums the
+    # matching slices of the gathered arrays; its own slice is also compared element for element)
+    gathered_ok = None
+    if gather is not None and args.steps > 0:
+        cdev = "cuda" if backend == "nccl" else "cpu"
+        lr, ls, le = wl.outs[(args.steps - 1) % len(wl.outs)]
+        mine = torch.stack([lr.to(torch.int64).sum(), le.sum(),
+                            ls.sum() if ls is not None else torch.zeros((), dtype=torch.int64,
+                                                                        device=lr.device)]).to(cdev)
+        sums = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(sums, mine)
+        if rank == 0:
+            gr, gs, ge = gather.last
+            gathered_ok = gr.numel() == world * n
+            for k in range(world if gathered_ok else 0):
+                sl = slice(k * n, (k + 1) * n)
+                got = [int(gr[sl].to(torch.int64).sum()), int(ge[sl].sum()),
+                       int(gs[sl].sum()) if gs is not None else 0]
+                gathered_ok = gathered_ok and got == [int(x) for x in sums[k].tolist()]
+            gathered_ok = gathered_ok and bool((gr[:n].to(lr.device) == lr).all()) and \
+                bool((ge[:n].to(le.device) == le).all())
+            bit_exact = bit_exact and gathered_ok
+
     # ---- dominant kernel's average launch duration: HIP events on its launch stream --------------
     # One stream, launches back to back, one event before the first and one after the last:
     # elapsed / launches = the kernel's duration plus the ~1.5 us gap between dependent launches -
@@ -652,6 +676,9 @@ def main():
                                    "weak-scaling reference for this line")
     if gather is not None:
         line["gathered_steps"] = gather.finished
+        line["gathered_matches_ranks"] = gathered_ok
+        line["gathered_check"] = ("last step: per-rank sums of result / start / end vs the sums of the "
+                                  "matching slices on the root; the root's own slice element for element")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args, wl, oracle)
     if rank == 0:

@@ -126,6 +126,11 @@ typedef struct redgpu_info {
                              time: long lines may be cut into speculatively walked chunks */
   uint32_t image_refs;    /* handles currently sharing this handle's device image (the loader
                              cache: same blob + device + build options -> one repack, one upload) */
+  uint32_t suffix_closed; /* 1 if the DFA accepts behind any prefix whatever it accepts (L = SIGMA* L:
+                             patterns added with a loose start).  scan / search / collect then stop at
+                             the first attempt that reaches the end of the line without accepting -
+                             no later start position can accept; the reference walks them all
+                             (include/Matcher.h:511-553, :575-621) to the same result */
 } redgpu_info;
 
 /* Replaces checkHeader (include/Serializer.h:109, lib/Serializer.cpp:270-298): returns

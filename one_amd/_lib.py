@@ -31,7 +31,8 @@ class Info(C.Structure):
                 ("max_result", C.c_int32), ("device", C.c_int32), ("checksum", C.c_uint32),
                 ("fast_path", C.c_uint32), ("n_hot", C.c_uint32), ("hot_lo", C.c_uint32),
                 ("hot_coverage_ppm", C.c_uint32), ("early_death", C.c_uint32),
-                ("forgetful", C.c_uint32), ("image_refs", C.c_uint32)]
+                ("forgetful", C.c_uint32), ("image_refs", C.c_uint32),
+                ("suffix_closed", C.c_uint32)]
 
 
 def build(force: bool = False) -> str:

@@ -487,6 +487,36 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
     }
   }
 
+  // L = SIGMA* L ?  (dfa_image.h: suffixClosed)  For every class c the language of the initial
+  // state must be included in that of next(init, c): walk the product from (init, next(init, c)),
+  // fail on a pair whose left accepts and whose right does not.  Pairs (x, x) hold trivially.
+  // Bounded: a DFA that needs more than 4 M pair visits is left unflagged.
+  {
+    const uint32_t n = img.nStates;
+    bool closed = img.maxResult > 0 && n <= 8192;
+    std::vector<uint64_t> seen;
+    std::vector<std::pair<uint32_t, uint32_t>> todo;
+    uint64_t visits = 0;
+    if (closed) seen.assign((size_t(n) * n + 63) / 64, 0);
+    auto push = [&](uint32_t x, uint32_t y) {
+      if (x == y) return;
+      const size_t bit = size_t(x) * n + y;
+      if (seen[bit >> 6] >> (bit & 63) & 1u) return;
+      seen[bit >> 6] |= 1ull << (bit & 63);
+      todo.emplace_back(x, y);
+    };
+    for (uint32_t c = 0; closed && c < nCls; ++c) push(img.init, img.next[size_t(img.init) * nCls + c]);
+    while (closed && !todo.empty()) {
+      const auto [x, y] = todo.back();
+      todo.pop_back();
+      if (++visits > (4u << 20)) { closed = false; break; }
+      if (img.result[x] > 0 && !(img.result[y] > 0)) { closed = false; break; }
+      for (uint32_t c = 0; c < nCls; ++c)
+        push(img.next[size_t(x) * nCls + c], img.next[size_t(y) * nCls + c]);
+    }
+    img.suffixClosed = closed;
+  }
+
   auto put = [&](size_t idx, uint32_t v, uint32_t width) {
     if (width == 1) img.table[idx] = uint8_t(v);
     else if (width == 2) { uint16_t x = uint16_t(v); std::memcpy(&img.table[idx * 2], &x, 2); }

@@ -85,6 +85,12 @@ struct DfaImage {
   // base[state] + class and fall back to sparseDefault when the owner is somebody else
   uint32_t sparseCombOff = 0, sparseDefault = 0;
   uint32_t hotCoveragePpm = 0;    // modelled share of visits landing on hot rows
+  // L = SIGMA* L: whatever the DFA accepts it also accepts behind any prefix (a pattern added
+  // with a loose start).  Then an attempt of scan / search that walked to the end of the line
+  // without an accepting state proves that no later start position can accept either (the
+  // text it would read is a suffix of what this attempt read), and the sliding loop can stop.
+  // Decided by language inclusion L(init) <= L(next(init, c)) for every class c (product walk).
+  bool     suffixClosed = false;
   bool     forgetful = false;     // the model's walk is back in the initial state most of the
                                   // time (>= 70 % of its mass after 64 bytes): chunks of a line
                                   // may be walked from the initial state as a guess (k_chunk.h)

@@ -225,6 +225,7 @@ struct LaneCtx {
   // start bytes of scan / search attempts (DevDfa): [0] without the leader, [1] with it
   uint32_t startWord[2] = {0, 0}, startCount[2] = {0xff, 0xff};
   uint32_t start2Word[2] = {0, 0}, start2Count[2] = {0xff, 0xff};  // ... and of their second bytes
+  uint32_t suffixClosed = 0;  // DevDfa::suffixClosed: a failed attempt at the end of the line ends the scan
   __device__ __forceinline__ int32_t resultOf(uint32_t s) const {
     return s >= firstAccept ? res[s] : 0;
   }
@@ -888,6 +889,7 @@ k_generic(DevDfa d, Batch b, int style, int lead) {
   c.startWord[1] = d.startLeadWord; c.startCount[1] = d.startLeadCount;
   c.start2Word[0] = d.start2FreeWord; c.start2Count[0] = d.start2FreeCount;
   c.start2Word[1] = d.start2LeadWord; c.start2Count[1] = d.start2LeadCount;
+  c.suffixClosed = d.suffixClosed;
 
   const uint64_t step = uint64_t(gridDim.x) * kGenericThreads;
   // ragged lines bucketed by length (k_ragged.h): a wave's 64 lines then end together
@@ -1629,6 +1631,7 @@ k_collect(DevDfa d, Batch b, uint64_t cap, uint64_t *counts) {
   c.startWord[1] = d.startLeadWord; c.startCount[1] = d.startLeadCount;
   c.start2Word[0] = d.start2FreeWord; c.start2Count[0] = d.start2FreeCount;
   c.start2Word[1] = d.start2LeadWord; c.start2Count[1] = d.start2LeadCount;
+  c.suffixClosed = d.suffixClosed;
   const uint64_t step = uint64_t(gridDim.x) * kThreads;
   for (uint64_t line = uint64_t(blockIdx.x) * kThreads + threadIdx.x; line < b.n; line += step) {
     const uint8_t *p;
@@ -1672,8 +1675,11 @@ k_collect(DevDfa d, Batch b, uint64_t cap, uint64_t *counts) {
         uint64_t q = i + 1;
         bool alive = true;
         for (uint32_t k = 0; k < 6 && q < n && alive; ++k, ++q) alive = stepOne(uint32_t(p[q]), q);
-        if (alive) walkBytes(p, q, n, stepOne);
-        if (!any) return true;
+        if (alive) {
+          // (walkBytes stops when stepOne says so: alive = the walk reached the end of the line)
+          walkBytes(p, q, n, [&](uint32_t b2, uint64_t q2) -> bool { return alive = stepOne(b2, q2); });
+        }
+        if (!any) return !(c.suffixClosed && alive);  // L = SIGMA* L: no later start can match either
         got = true; accS = aS; mS = ms; mE = me;
         return false;
       });
@@ -1751,6 +1757,7 @@ k_matchall(DevDfa d, Batch b, uint64_t cap, uint64_t *counts, int lead) {
   c.startWord[1] = d.startLeadWord; c.startCount[1] = d.startLeadCount;
   c.start2Word[0] = d.start2FreeWord; c.start2Count[0] = d.start2FreeCount;
   c.start2Word[1] = d.start2LeadWord; c.start2Count[1] = d.start2LeadCount;
+  c.suffixClosed = d.suffixClosed;
   const uint64_t step = uint64_t(gridDim.x) * kThreads;
   for (uint64_t line = uint64_t(blockIdx.x) * kThreads + threadIdx.x; line < b.n; line += step) {
     const uint8_t *p;
@@ -2016,6 +2023,7 @@ k_advance(DevDfa d, Batch b, uint32_t *state) {
   c.startWord[1] = d.startLeadWord; c.startCount[1] = d.startLeadCount;
   c.start2Word[0] = d.start2FreeWord; c.start2Count[0] = d.start2FreeCount;
   c.start2Word[1] = d.start2LeadWord; c.start2Count[1] = d.start2LeadCount;
+  c.suffixClosed = d.suffixClosed;
   const uint64_t step = uint64_t(gridDim.x) * kThreads;
   for (uint64_t line = uint64_t(blockIdx.x) * kThreads + threadIdx.x; line < b.n; line += step) {
     const uint8_t *p;
@@ -2114,6 +2122,7 @@ k_replace(DevDfa d, Batch b, int style, int lead, const uint8_t *repl, uint64_t 
   c.startWord[1] = d.startLeadWord; c.startCount[1] = d.startLeadCount;
   c.start2Word[0] = d.start2FreeWord; c.start2Count[0] = d.start2FreeCount;
   c.start2Word[1] = d.start2LeadWord; c.start2Count[1] = d.start2LeadCount;
+  c.suffixClosed = d.suffixClosed;
   const uint64_t step = uint64_t(gridDim.x) * kThreads;
   for (uint64_t line = uint64_t(blockIdx.x) * kThreads + threadIdx.x; line < b.n; line += step) {
     const uint8_t *p;
@@ -3130,6 +3139,17 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
     return hipSuccess;
   }
   const bool lead = doLeader && d.leaderLen > 0;
+  // L = SIGMA* L (DfaImage::suffixClosed - patterns added with a loose start) and no leader: the
+  // sliding loops of scan and search (Matcher.h:511-553, :575-621) ARE their first attempt.  It
+  // cannot meet a pure dead end (from any reachable state something is still accepted), so it
+  // either returns per the style's rules - as check / match from position 0 would, same loop
+  // body - or reads the line to its end without an accepting state, and then no later start
+  // position can accept either: the text it would read is a suffix of what this attempt read.
+  // The reference walks every one of them (O(n^2) on a line without a match) to that same 0.
+  if (d.suffixClosed && !lead) {
+    if (verb == kScan) verb = kCheck;
+    else if (verb == kSearch) verb = kMatch;
+  }
   // DFAs the visit model sees dying within 16 bytes (anchored patterns on arbitrary text) stay
   // with k_generic: the whole-line kernels below read and walk every byte, k_generic stops
   // where the reference's loop stops - measured on ERR 1.3x (64-byte lines) to 38x (4 KiB

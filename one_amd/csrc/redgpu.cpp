@@ -326,6 +326,7 @@ int uploadImage(SharedImage *im) {
   d.sparseDefault = img.sparseDefault;
   d.tuned = img.tuned ? 1 : 0;
   d.forgetful = img.forgetful ? 1 : 0;
+  d.suffixClosed = img.suffixClosed ? 1 : 0;
   {
     const char *e = getenv("REDGPU_GATHER_NT");
     d.gatherNt = e && e[0] == '1';
@@ -489,6 +490,7 @@ int redgpu_dfa_info(const redgpu_dfa *h, redgpu_info *out) {
   out->hot_coverage_ppm = img.hotCoveragePpm;
   out->early_death = img.earlyDeath ? 1 : 0;
   out->forgetful = img.forgetful ? 1 : 0;
+  out->suffix_closed = img.suffixClosed ? 1 : 0;
   out->image_refs = uint32_t(h->im.use_count());
   return REDGPU_OK;
 }

@@ -160,3 +160,11 @@ def test_loader_cache_shares_images():
     a.close()
     f = one_amd.Executable(blob, device="none")                          # rebuilt from scratch
     assert f.info["image_refs"] == 1 and f.serialized() == blob
+
+
+def test_suffix_closed_flag_host_side():
+    """redgpu_info.suffix_closed (L = SIGMA* L, decided by language inclusion on the repacked DFA):
+    set for the loose-start DFAs, clear for anchored and random ones."""
+    for name, want in (("uri", 1), ("newyork", 1), ("dotstar_err", 1), ("uri_v6", 1), ("err", 0),
+                       ("aab", 0), ("num3", 0), ("syn256", 0), ("log100", 0)):
+        assert one_amd.Executable(load_dfa(name), device="none").info["suffix_closed"] == want, name

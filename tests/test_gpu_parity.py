@@ -310,6 +310,56 @@ def test_hot_row_tables_vs_oracle(rows):
             assert np.array_equal(e, vec[key + "end"])
 
 
+@pytest.mark.parametrize("name", ["uri", "newyork", "dotstar_err", "uri_user"])
+def test_loose_start_scan_search_collect_vs_oracle(name):
+    """DFAs with L = SIGMA* L (redgpu_info.suffix_closed: patterns added with a loose start): scan,
+    search and collect stop at the first attempt that reaches the end of the line without
+    accepting - the reference's loop (Matcher.h:511-553, :575-621) walks every later start
+    position to the same answer.  Lines with no match, a match at the start / middle / very end,
+    several matches, empty lines, every style; fixed strides too."""
+    blob = load_dfa(name)
+    exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
+    assert exe.info["suffix_closed"] == 1
+    assert one_amd.Executable(load_dfa("err")).info["suffix_closed"] == 0
+    rng = np.random.default_rng(11)
+    plants = [W.URI_PLANT, b"New York", b"error", b"York", b"ftp://a.bc/", b"New"]
+    lens = list(rng.integers(0, 300, 2500)) + [0, 1, 2, 700, 0, 33]
+    offsets = np.zeros(len(lens) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    data = W.alphabet_bytes(int(offsets[-1]), 77)[: int(offsets[-1])].copy()
+    for li in range(0, len(lens), 3):  # every third line gets a plant somewhere (or at its end)
+        pl = np.frombuffer(plants[(li // 3) % len(plants)], dtype=np.uint8)
+        L = lens[li]
+        if L < len(pl):
+            continue
+        at = [0, (L - len(pl)) // 2, L - len(pl)][(li // 3) % 3]
+        o = int(offsets[li]) + at
+        data[o:o + len(pl)] = pl
+    for si in range(1, 6):
+        exp = cpu.batch("scan", si, 0, data, offsets=offsets, threads=4)[0]
+        assert np.array_equal(one_amd.scan_batch(exe, data, si, 0, offsets=offsets), exp), (name, si)
+        er, es, ee = cpu.batch("search", si, 0, data, offsets=offsets, threads=4)
+        r, s, e = one_amd.search_batch(exe, data, si, 0, offsets=offsets)
+        assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee), (name, si)
+        assert np.array_equal(one_amd.scan_batch(exe, data, si, 1, offsets=offsets),
+                              cpu.batch("scan", si, 1, data, offsets=offsets, threads=4)[0])
+    counts, res, st, en = one_amd.collect_batch(exe, data, 3, offsets=offsets)
+    ec, er3, es3, ee3 = cpu.collect_batch(data, 3, offsets=offsets)
+    assert np.array_equal(counts, ec), name
+    mask = np.arange(3)[None, :] < np.minimum(counts, 3).astype(np.int64)[:, None]  # filled slots
+    assert np.array_equal(res[mask], np.asarray(er3)[mask]) and np.array_equal(st[mask], np.asarray(es3)[mask])
+    assert np.array_equal(en[mask], np.asarray(ee3)[mask]), name
+    n, L = 1500, 96
+    fixed = W.alphabet_bytes(n * L, 5)[: n * L].copy()
+    fixed.reshape(n, L)[::4, 40:40 + len(W.URI_PLANT)] = np.frombuffer(W.URI_PLANT, dtype=np.uint8)
+    for si in (1, 4, 5):
+        assert np.array_equal(one_amd.scan_batch(exe, fixed, si, 0, stride=L, n=n),
+                              cpu.batch("scan", si, 0, fixed, stride=L, n=n, threads=4)[0])
+        er, es, ee = cpu.batch("search", si, 0, fixed, stride=L, n=n, threads=4)
+        r, s, e = one_amd.search_batch(exe, fixed, si, 0, stride=L, n=n)
+        assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee)
+
+
 @pytest.mark.parametrize("name", ["err", "aab", "num3"])  # anchored: scan stays linear on the long line
 def test_marked_scan_and_search_vs_oracle(name):
     """k_scan_marked (scan / search; DFAs with <= 4 start bytes through the packed list, num3 -

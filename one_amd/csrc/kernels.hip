@@ -2068,10 +2068,12 @@ __device__ uint64_t replaceLane(const T &tab, const LaneCtx &c, const uint8_t *p
       break;
     }
     uint64_t found = ~0ull;
+    bool toEnd = false;  // the attempt read p[in..n) to its end
     if (!lead || lookingAt(c, p, in, n)) {
       uint32_t s = c.init;
       int32_t prev = 0;
-      for (uint64_t q = in; q < n; ++q) {
+      uint64_t q = in;
+      for (; q < n; ++q) {
         s = tab.next(s, p[q]);
         if (s >= c.firstAccept) {
           const int32_t r = c.res[s];
@@ -2088,6 +2090,15 @@ __device__ uint64_t replaceLane(const T &tab, const LaneCtx &c, const uint8_t *p
             break;
         }
       }
+      toEnd = q == n;
+    }
+    if (found == ~0ull && toEnd && c.suffixClosed && !lead) {
+      // L = SIGMA* L: nothing matched on p[in..n), so nothing can at any later position (they read
+      // suffixes of it) - the rest of the line is copied as the reference's loop would, byte by byte
+      if (out)
+        for (uint64_t k = in; k < n; ++k) out[w + (k - in)] = p[k];
+      w += n - in;
+      break;
     }
     if (found != ~0ull) {
       if (out)

@@ -1,0 +1,7 @@
+#!/bin/bash
+set -u
+mkdir -p gpurun_out
+timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py -q -x -k "replace or all_verbs or vectors or loose" > gpurun_out/r2_tmp.log 2>&1 || { tail -40 gpurun_out/r2_tmp.log; exit 1; }
+tail -1 gpurun_out/r2_tmp.log
+timeout -k 10 500 python3 scripts/fuzz_gpu.py 400 51 > gpurun_out/r2_fuzz.log 2>&1 || { tail -30 gpurun_out/r2_fuzz.log; exit 1; }
+tail -1 gpurun_out/r2_fuzz.log | cut -c1-200

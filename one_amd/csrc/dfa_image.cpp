@@ -515,6 +515,14 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
         push(img.next[size_t(x) * nCls + c], img.next[size_t(y) * nCls + c]);
     }
     img.suffixClosed = closed;
+    int32_t one = 0;
+    bool uniform = true;
+    for (uint32_t i = 0; i < n && uniform; ++i)
+      if (img.result[i] > 0) {
+        if (one == 0) one = img.result[i];
+        uniform = img.result[i] == one;
+      }
+    img.uniformResult = uniform && one > 0;
   }
 
   auto put = [&](size_t idx, uint32_t v, uint32_t width) {

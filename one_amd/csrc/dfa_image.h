@@ -91,6 +91,10 @@ struct DfaImage {
   // text it would read is a suffix of what this attempt read), and the sliding loop can stop.
   // Decided by language inclusion L(init) <= L(next(init, c)) for every class c (product walk).
   bool     suffixClosed = false;
+  // every accepting state reports the same result (a single pattern, or several under one id):
+  // check then answers the same for every style but styFull - whichever accepting state a style
+  // picks, its result is that one value
+  bool     uniformResult = false;
   bool     forgetful = false;     // the model's walk is back in the initial state most of the
                                   // time (>= 70 % of its mass after 64 bytes): chunks of a line
                                   // may be walked from the initial state as a guess (k_chunk.h)

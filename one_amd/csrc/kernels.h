@@ -35,6 +35,7 @@ struct DevDfa {
   uint32_t earlyDeath;           // the visit model sees walks die within 16 bytes
   uint32_t tuned;                // hot rows ranked by observed visits
   uint32_t forgetful;            // the walk is mostly in the initial state (k_chunk.h)
+  uint32_t uniformResult;        // every accepting state has the same result (dfa_image.h)
   uint32_t suffixClosed;         // L = SIGMA* L (dfa_image.h): a failed attempt that reached the end
                                  // of the line ends scan / search / collect
   uint32_t gatherNt;             // REDGPU_GATHER_NT=1: non-temporal table gathers (tuning experiment)

@@ -3161,6 +3161,13 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
     if (verb == kScan) verb = kCheck;
     else if (verb == kSearch) verb = kMatch;
   }
+  // check over a DFA whose accepting states all report ONE result (a single pattern): styInstant,
+  // styFirst and styTangent each return the result of SOME accepting state of the walk, styLast
+  // that of the last one - the same value, and 0 alike when none accepts (Matcher.h:382-409).
+  // styLast is the style the streaming kernels run; an early-death DFA keeps its early exits.
+  if (verb == kCheck && !lead && d.uniformResult && !d.earlyDeath && !cfg.forceGeneric &&
+      (style == kStyInstant || style == kStyFirst || style == kStyTangent))
+    style = kStyLast;
   // DFAs the visit model sees dying within 16 bytes (anchored patterns on arbitrary text) stay
   // with k_generic: the whole-line kernels below read and walk every byte, k_generic stops
   // where the reference's loop stops - measured on ERR 1.3x (64-byte lines) to 38x (4 KiB

@@ -327,6 +327,7 @@ int uploadImage(SharedImage *im) {
   d.tuned = img.tuned ? 1 : 0;
   d.forgetful = img.forgetful ? 1 : 0;
   d.suffixClosed = img.suffixClosed ? 1 : 0;
+  d.uniformResult = img.uniformResult ? 1 : 0;
   {
     const char *e = getenv("REDGPU_GATHER_NT");
     d.gatherNt = e && e[0] == '1';

@@ -568,6 +568,26 @@ def main():
             calib["result_end_only_how"] = ("the same batch and entry point with start = NULL (result + end, "
                                             "the outputs north_star names), %d launches back to back on one "
                                             "stream; `value` keeps the full Outcome" % reps)
+        # (c4) the path's other verb on the same batch: scan<styInstant,false> ("does the line contain
+        # a match") - for a loose-start DFA (redgpu_info.suffix_closed) it runs on the same kernels
+        if not wl.ragged and args.config in (1, 2) and info.get("suffix_closed"):
+            sres = torch.empty(n, dtype=torch.int32, device="cuda")
+            sargs = (wl.exe._h, int(one_amd.styInstant), 0, wl.bufs[0].data_ptr(), None, wl.L, n,
+                     sres.data_ptr(), cur_stream)
+            reps = 20 if args.config == 1 else 5
+            for _ in range(2):
+                l.redgpu_scan_batch_dev(*sargs)
+            c0.record()
+            for _ in range(reps):
+                l.redgpu_scan_batch_dev(*sargs)
+            c1.record()
+            torch.cuda.synchronize()
+            calib["scan_instant_GBps"] = round(reps * wl.in_bytes / (c0.elapsed_time(c1) * 1e-3) / 1e9, 1)
+            calib["scan_instant_kernel"] = one_amd.last_kernel()
+            # scan<styInstant> is non-zero exactly where match<styLast> is (single-result DFA)
+            l.redgpu_match_batch_dev(*wl.call_tuple(0, cur_stream))
+            torch.cuda.synchronize()
+            calib["scan_instant_agrees_with_match"] = bool(((sres != 0) == (wl.outs[0][0] != 0)).all())
         # (d) bytes the walk actually reads (early-exit DFAs)
         if info["early_death"] or wl.ragged:
             w = torch.zeros(1, dtype=torch.int64, device="cuda")

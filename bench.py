@@ -114,9 +114,10 @@ class Workload:
         if not args.no_tune and self.info["table_kind"] == 6 and not self.ragged:
             # REDGPU_TAB_HOT_ROWS: re-rank the LDS-resident rows by a sample of the input (outside
             # the timed region, like the upload; redgpu_dfa_tune)
-            # (the sample is walked as 1 KiB pieces: the visit histogram wants lanes, not whole lines)
+            # (the sample is walked as 16 KiB pieces: the visit histogram wants lanes, but a walk
+            # that restarts every KiB over-counts the states around the initial one)
             sample = min(self.n * self.L, 4 << 20)
-            piece = min(self.L, 1024)
+            piece = min(self.L, 16384)
             self.info = self.exe.tune(self.bufs[0][:sample], stride=piece, n=sample // piece)
             self.tuned = "hot rows re-ranked on the first %d bytes of buffer 0" % sample
 

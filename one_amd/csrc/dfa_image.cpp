@@ -490,7 +490,7 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
   // L = SIGMA* L ?  (dfa_image.h: suffixClosed)  For every class c the language of the initial
   // state must be included in that of next(init, c): walk the product from (init, next(init, c)),
   // fail on a pair whose left accepts and whose right does not.  Pairs (x, x) hold trivially.
-  // Bounded: a DFA that needs more than 4 M pair visits is left unflagged.
+  // Bounded: a DFA that needs more than 1 M pair visits is left unflagged.
   {
     const uint32_t n = img.nStates;
     bool closed = img.maxResult > 0 && n <= 8192;
@@ -509,7 +509,7 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
     while (closed && !todo.empty()) {
       const auto [x, y] = todo.back();
       todo.pop_back();
-      if (++visits > (4u << 20)) { closed = false; break; }
+      if (++visits > (1u << 20)) { closed = false; break; }
       if (img.result[x] > 0 && !(img.result[y] > 0)) { closed = false; break; }
       for (uint32_t c = 0; c < nCls; ++c)
         push(img.next[size_t(x) * nCls + c], img.next[size_t(y) * nCls + c]);

@@ -569,6 +569,36 @@ def main():
             calib["result_end_only_how"] = ("the same batch and entry point with start = NULL (result + end, "
                                             "the outputs north_star names), %d launches back to back on one "
                                             "stream; `value` keeps the full Outcome" % reps)
+        # (c5) the launch-bound shape under a HIP graph: 20 launches of the timed call captured once
+        # on one stream (the _dev entry points are stream-ordered, nothing in them synchronises or
+        # allocates on this path) and replayed - what the ~1.5 us gap between dependent launches costs
+        if args.config == 1 and not wl.ragged:
+            try:
+                gs = torch.cuda.Stream()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(gs):
+                    for i in range(3):
+                        fn(*wl.call_tuple(i, gs.cuda_stream))
+                gs.synchronize()
+                with torch.cuda.graph(graph, stream=gs):
+                    for i in range(20):
+                        rc = fn(*wl.call_tuple(i, torch.cuda.current_stream().cuda_stream))
+                        if rc != 0:
+                            raise RuntimeError(l.redgpu_last_error().decode())
+                graph.replay()
+                torch.cuda.synchronize()
+                c0.record()
+                for _ in range(5):
+                    graph.replay()
+                c1.record()
+                torch.cuda.synchronize()
+                calib["graph_replay_GBps"] = round(100 * wl.in_bytes / (c0.elapsed_time(c1) * 1e-3) / 1e9, 1)
+                calib["graph_replay_how"] = ("20 launches captured in one HIP graph on one stream, replayed "
+                                             "5 times (same entry point, rotating buffers)")
+                del graph
+            except Exception as ex:  # capture is evidence, not the product path
+                calib["graph_replay_GBps"] = None
+                calib["graph_replay_error"] = str(ex)[:200]
         # (c4) the path's other verb on the same batch: scan<styInstant,false> ("does the line contain
         # a match") - for a loose-start DFA (redgpu_info.suffix_closed) it runs on the same kernels
         if not wl.ragged and args.config in (1, 2) and info.get("suffix_closed"):

@@ -971,7 +971,7 @@ __device__ __forceinline__ uint32_t earlyHave(uint64_t n) {
 // reload) 415 -> 345 us; two or four pieces (fewer reloads: 1.6 GB instead of 2.1 GB missing L2)
 // 346 / 377 us - no faster; 1024-thread workgroups (32 waves per CU) 363 us; the drain's next
 // two pieces requested together 360 us (scripts/gpu_run17.sh).
-template <int KIND, class WALK, int LPL, int WPS, int PC, int THREADS>
+template <int KIND, class WALK, int LPL, int WPS, int PC, int THREADS, bool LEAN_DRAIN>
 __global__ void __launch_bounds__(THREADS, WPS)
 k_early(DevDfa d, Batch b, int style, int lead) {
   constexpr uint32_t kEarlyChunk = THREADS * LPL;
@@ -1087,6 +1087,39 @@ k_early(DevDfa d, Batch b, int style, int lead) {
       const uint64_t ln = chunk * kEarlyChunk + (en.x & 0xfffu);
       uint64_t oo, nl;
       spanOf(ln, oo, nl);
+      if constexpr (LEAN_DRAIN) {
+        // the lean walk without a branch per byte: a piece's 16 steps are selects under the
+        // lane's `alive` flag (a lane that has met its pure dead end changes nothing any more),
+        // the loop asks once per piece; positions in 32 bits (longer lines: the walk below)
+        if (nl < (1ull << 32)) {
+          uint32_t st = w.s, accS = w.accS, ms = uint32_t(w.matchStart), me = uint32_t(w.matchEnd);
+          uint32_t pos = earlyHave<PC>(nl);
+          const uint32_t n32 = uint32_t(nl);
+          const uint8_t *p = b.data + oo;
+          bool alive = true;
+          auto lean = [&](uint32_t byte, uint32_t idx) {
+            const uint32_t s2 = tab.next(st, byte);
+            const bool leaves = st == c.init && s2 != st;
+            const bool acc = s2 >= c.firstAccept;
+            ms = alive && leaves ? idx : ms;
+            accS = alive && acc ? s2 : accS;
+            me = alive && acc ? idx + 1 : me;
+            st = alive ? s2 : st;
+            alive = alive && (acc || s2 >= c.nPureDead);
+          };
+          while (alive && pos + 16 <= n32) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(p + pos);
+            const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (uint32_t k = 0; k < 16; ++k) lean((words[k >> 2] >> (8 * (k & 3))) & 0xffu, pos + k);
+            pos += 16;
+          }
+          for (; alive && pos < n32; ++pos) lean(uint32_t(p[pos]), pos);
+          w.s = st; w.accS = accS; w.matchStart = ms; w.matchEnd = me;
+          store(ln, w);
+          continue;
+        }
+      }
       walkBytes(b.data + oo, earlyHave<PC>(nl), nl,
                 [&](uint32_t byte, uint64_t idx) { return w.step(tab, c, style, byte, idx); });
       store(ln, w);
@@ -2504,12 +2537,12 @@ hipError_t launchGeneric(const DevDfa &d, const Batch &b, int verb, int style, i
   return hipGetLastError();
 }
 
-template <int KIND, class WALK, int LPL, int WPS, int PC = 1, int THREADS = 512>
+template <int KIND, class WALK, int LPL, int WPS, int PC = 1, int THREADS = 512, bool LEAN_DRAIN = false>
 hipError_t launchEarlyV(const DevDfa &d, const Batch &b, int style, int lead, const LaunchCfg &cfg,
                         hipStream_t stream) {
   const size_t tabBytes = (tableOnlyBytes<KIND>(d) + 15) & ~size_t(15);
   const size_t ldsBytes = 512 + tabBytes + size_t(THREADS) * LPL * 16;
-  hipError_t e = setLds(k_early<KIND, WALK, LPL, WPS, PC, THREADS>, ldsBytes);
+  hipError_t e = setLds(k_early<KIND, WALK, LPL, WPS, PC, THREADS, LEAN_DRAIN>, ldsBytes);
   if (e != hipSuccess) return e;
   // as many workgroups per CU as LDS and the register budget allow (their probe / drain phases
   // overlap each other's memory round trips)
@@ -2521,7 +2554,7 @@ hipError_t launchEarlyV(const DevDfa &d, const Batch &b, int style, int lead, co
   const uint64_t chunks = (b.n + chunk - 1) / chunk;
   uint64_t blocks = uint64_t(cfg.numCUs) * perCu;
   if (blocks > chunks) blocks = chunks;
-  hipLaunchKernelGGL((k_early<KIND, WALK, LPL, WPS, PC, THREADS>), dim3(uint32_t(blocks)), dim3(THREADS),
+  hipLaunchKernelGGL((k_early<KIND, WALK, LPL, WPS, PC, THREADS, LEAN_DRAIN>), dim3(uint32_t(blocks)), dim3(THREADS),
                      ldsBytes, stream, d, b, style, lead);
   return hipGetLastError();
 }
@@ -2531,7 +2564,8 @@ hipError_t launchEarlyK(const DevDfa &d, const Batch &b, int verb, int style, in
                         const LaunchCfg &cfg, hipStream_t stream) {
   if (verb == kCheck) return launchEarlyV<KIND, CheckWalk, 2, 4>(d, b, style, 0, cfg, stream);
   if (style != kStyLast) return launchEarlyV<KIND, AnyWalk, 2, 4>(d, b, style, lead, cfg, stream);
-  return launchEarlyV<KIND, LastWalk, 2, 6>(d, b, style, lead, cfg, stream);
+  // (the drain without a branch per byte: configs[3] 350 -> 337 us, scripts/gpu_run37.sh)
+  return launchEarlyV<KIND, LastWalk, 2, 6, 1, 512, true>(d, b, style, lead, cfg, stream);
 }
 
 template <int KIND>

@@ -1575,6 +1575,15 @@ k_fixed(DevDfa d, Batch b, uint32_t lineLen, uint32_t startByte, uint32_t startS
       cur[c] = *reinterpret_cast<const uint4 *>(lp[c] + startByte);
 
     for (uint32_t off = startByte; off < lineLen; off += 16) {
+      if constexpr (STYLE != kStyLast && STYLE != kStyFull) {
+        // the early-exit styles: once the reference's loop has left every line this wave holds,
+        // the rest of those lines is not read (a dense DFA under styInstant is done within its
+        // first piece: SYN-256 on 4 KiB lines 1.3 -> 39 TB/s of line bytes, as k_generic already did)
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) any = any || cs[c].live != 0;
+        if (!__builtin_amdgcn_ballot_w64(any)) break;
+      }
       uint4 nxt[CHAINS];
       const bool more = off + 16 < lineLen;
       if (more) {

@@ -1876,6 +1876,84 @@ __device__ __forceinline__ void mabBook(uint32_t s, uint32_t &accR, uint32_t &in
                : [s] "v"(s), [T] "s"(T), [init] "s"(init));
 }
 
+// Phase A of the block kernels (k_matchall_blocks, k_style_blocks): walks up to kPos = 64 / W
+// positions of a line from p (rem = bytes left in the line), straight-line, and leaves behind
+//   acc / ini : one bit per position - the state after it is accepting / is the initial state;
+//   stage     : the states themselves, W bytes each, lane-interleaved in LDS
+//               (word w of lane t at stage[w * THREADS + t]: no bank conflicts);
+//   s         : the state after the last position walked.
+// Returns the number of positions walked (kPos, or all that was left of the line).
+template <int KIND, int THREADS, int W>
+__device__ __forceinline__ uint32_t mabWalkBlock(const Tab<KIND> &tab, const LaneCtx &c,
+                                                 const uint8_t *p, uint64_t rem, uint32_t &s,
+                                                 uint32_t *stage, bool tableAt512, uint64_t &acc,
+                                                 uint64_t &ini) {
+  constexpr uint32_t kPos = 64 / W;
+  constexpr uint32_t kPerWord = 4 / W;
+  const uint32_t nq = rem >= kPos ? kPos / 16 : uint32_t(rem >> 4);  // whole 16-byte pieces
+  uint4 piece[kPos / 16];
+#pragma unroll
+  for (uint32_t q = 0; q < kPos / 16; ++q)
+    piece[q] = q < nq ? *reinterpret_cast<const uint4 *>(p + 16 * q) : make_uint4(0, 0, 0, 0);
+  bool walked = false;
+  if constexpr (KIND == REDGPU_TAB_LDS_FUSED_U8 && W == 1) {
+    if (nq == kPos / 16 && tableAt512) {
+      // a whole block over the fused table: mabStep, masks first-position-high, two halves
+      uint32_t aR[2] = {0, 0}, iR[2] = {0, 0}, packed = 0;
+#pragma unroll
+      for (uint32_t pos = 0; pos < 64; ++pos) {
+        const uint4 &pc = piece[pos >> 4];
+        const uint32_t word = (pos >> 2) % 4 == 0 ? pc.x : (pos >> 2) % 4 == 1 ? pc.y
+                              : (pos >> 2) % 4 == 2 ? pc.z : pc.w;
+        const uint32_t sel = 0x0c0c0400u + (pos & 3u);
+        // the bookkeeping inside step `pos` is for position pos - 1
+        if (pos == 0) mabStep<false>(s, word, sel, aR[0], iR[0], packed, c.firstAccept, c.init);
+        else mabStep<true>(s, word, sel, aR[(pos - 1) >> 5], iR[(pos - 1) >> 5], packed,
+                           c.firstAccept, c.init);
+        if (pos && pos % 4 == 0) stage[(pos / 4 - 1) * THREADS + threadIdx.x] = packed;
+      }
+      mabBook(s, aR[1], iR[1], packed, c.firstAccept, c.init);
+      stage[15 * THREADS + threadIdx.x] = packed;
+      acc = (uint64_t(__builtin_bitreverse32(aR[1])) << 32) | __builtin_bitreverse32(aR[0]);
+      ini = (uint64_t(__builtin_bitreverse32(iR[1])) << 32) | __builtin_bitreverse32(iR[0]);
+      walked = true;
+    }
+  }
+#pragma unroll
+  for (uint32_t q = 0; q < kPos / 16; ++q) {
+    if (!walked && q < nq) {
+      const uint32_t words[4] = {piece[q].x, piece[q].y, piece[q].z, piece[q].w};
+      uint32_t packed = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < 16; ++k) {
+        const uint32_t pos = 16 * q + k;
+        s = tab.next(s, (words[k >> 2] >> (8 * (k & 3))) & 0xffu);
+        acc |= s >= c.firstAccept ? 1ull << pos : 0ull;
+        ini |= s == c.init ? 1ull << pos : 0ull;
+        packed |= s << (8 * W * (pos % kPerWord));
+        if (pos % kPerWord == kPerWord - 1) {
+          stage[(pos / kPerWord) * THREADS + threadIdx.x] = packed;
+          packed = 0;
+        }
+      }
+    }
+  }
+  uint32_t cnt = 16 * nq;
+  if (cnt < kPos && cnt < rem) {  // the last < 16 bytes of the line
+    const uint32_t last = uint32_t(rem);  // < kPos here
+    for (; cnt < last; ++cnt) {
+      s = tab.next(s, uint32_t(p[cnt]));
+      acc |= uint64_t(s >= c.firstAccept) << cnt;
+      ini |= uint64_t(s == c.init) << cnt;
+      uint8_t *slot = reinterpret_cast<uint8_t *>(stage) +
+                      (((cnt / kPerWord) * THREADS + threadIdx.x) << 2) + W * (cnt % kPerWord);
+      if (W == 1) *slot = uint8_t(s);
+      else *reinterpret_cast<uint16_t *>(slot) = uint16_t(s);
+    }
+  }
+  return cnt;
+}
+
 // =========================================================================================
 // k_matchall_blocks: matchAllCore (include/Matcher.h:711-766) in two phases per block of a line.
 //
@@ -1931,71 +2009,11 @@ k_matchall_blocks(DevDfa d, Batch b, uint64_t cap, uint64_t *counts, int lead) {
     int32_t prevR = 0;       // result at the last position of the block before, 0 if it did not accept
     uint64_t matchStart = 0, found = 0, curEnd = 0;
     for (uint64_t base = 0; base < n; base += kPos) {
-      const uint64_t rem = n - base;
-      const uint32_t nq = rem >= kPos ? kPos / 16 : uint32_t(rem >> 4);  // whole 16-byte pieces
-      uint64_t acc = 0, ini = 0;
       const uint64_t wasInit = s == c.init ? 1u : 0u;
-      // ---- A: the walk -------------------------------------------------------------------------
-      uint4 piece[kPos / 16];
-#pragma unroll
-      for (uint32_t q = 0; q < kPos / 16; ++q)
-        piece[q] = q < nq ? *reinterpret_cast<const uint4 *>(p + base + 16 * q) : make_uint4(0, 0, 0, 0);
-      bool walked = false;
-      if constexpr (KIND == REDGPU_TAB_LDS_FUSED_U8 && W == 1) {
-        if (nq == kPos / 16 && tableAt512) {
-          // a whole block over the fused table: mabStep, masks first-position-high, two halves
-          uint32_t aR[2] = {0, 0}, iR[2] = {0, 0}, packed = 0;
-#pragma unroll
-          for (uint32_t pos = 0; pos < 64; ++pos) {
-            const uint4 &pc = piece[pos >> 4];
-            const uint32_t word = (pos >> 2) % 4 == 0 ? pc.x : (pos >> 2) % 4 == 1 ? pc.y
-                                  : (pos >> 2) % 4 == 2 ? pc.z : pc.w;
-            const uint32_t sel = 0x0c0c0400u + (pos & 3u);
-            // the bookkeeping inside step `pos` is for position pos - 1
-            if (pos == 0) mabStep<false>(s, word, sel, aR[0], iR[0], packed, c.firstAccept, c.init);
-            else mabStep<true>(s, word, sel, aR[(pos - 1) >> 5], iR[(pos - 1) >> 5], packed,
-                               c.firstAccept, c.init);
-            if (pos && pos % 4 == 0) stage[(pos / 4 - 1) * THREADS + threadIdx.x] = packed;
-          }
-          mabBook(s, aR[1], iR[1], packed, c.firstAccept, c.init);
-          stage[15 * THREADS + threadIdx.x] = packed;
-          acc = (uint64_t(__builtin_bitreverse32(aR[1])) << 32) | __builtin_bitreverse32(aR[0]);
-          ini = (uint64_t(__builtin_bitreverse32(iR[1])) << 32) | __builtin_bitreverse32(iR[0]);
-          walked = true;
-        }
-      }
-#pragma unroll
-      for (uint32_t q = 0; q < kPos / 16; ++q) {
-        if (!walked && q < nq) {
-          const uint32_t words[4] = {piece[q].x, piece[q].y, piece[q].z, piece[q].w};
-          uint32_t packed = 0;
-#pragma unroll
-          for (uint32_t k = 0; k < 16; ++k) {
-            const uint32_t pos = 16 * q + k;
-            s = tab.next(s, (words[k >> 2] >> (8 * (k & 3))) & 0xffu);
-            acc |= s >= c.firstAccept ? 1ull << pos : 0ull;
-            ini |= s == c.init ? 1ull << pos : 0ull;
-            packed |= s << (8 * W * (pos % kPerWord));
-            if (pos % kPerWord == kPerWord - 1) {
-              stage[(pos / kPerWord) * THREADS + threadIdx.x] = packed;
-              packed = 0;
-            }
-          }
-        }
-      }
-      uint32_t cnt = 16 * nq;
-      if (cnt < kPos && cnt < rem) {  // the last < 16 bytes of the line
-        const uint32_t last = uint32_t(rem);  // < kPos here
-        for (; cnt < last; ++cnt) {
-          s = tab.next(s, uint32_t(p[base + cnt]));
-          acc |= uint64_t(s >= c.firstAccept) << cnt;
-          ini |= uint64_t(s == c.init) << cnt;
-          uint8_t *slot = reinterpret_cast<uint8_t *>(stage) +
-                          (((cnt / kPerWord) * THREADS + threadIdx.x) << 2) + W * (cnt % kPerWord);
-          if (W == 1) *slot = uint8_t(s);
-          else *reinterpret_cast<uint16_t *>(slot) = uint16_t(s);
-        }
-      }
+      uint64_t acc = 0, ini = 0;
+      // ---- A: the walk (mabWalkBlock) ------------------------------------------------------------
+      const uint32_t cnt = mabWalkBlock<KIND, THREADS, W>(tab, c, p + base, n - base, s, stage,
+                                                          tableAt512, acc, ini);
       // ---- B: the accepting positions ----------------------------------------------------------
       const uint64_t valid = cnt >= 64 ? ~0ull : (1ull << cnt) - 1;
       const uint64_t esc = (((ini << 1) | wasInit) & ~ini) & valid;  // "left the initial state" here
@@ -2044,6 +2062,128 @@ k_matchall_blocks(DevDfa d, Batch b, uint64_t cap, uint64_t *counts, int lead) {
     }
     if (found && found - 1 < cap && en) en[found - 1] = curEnd;
     counts[line] = found;
+  }
+}
+
+// =========================================================================================
+// k_style_blocks: check / match with the EARLY-EXIT styles (styInstant, styFirst, styTangent;
+// include/Matcher.h:382-403, :443-479), no leader, over the same two phases as k_matchall_blocks.
+// What those styles report is decided by the FIRST run of accepting positions:
+//   styInstant : the first accepting position a0 - result of its state, end = a0 + 1;
+//   styTangent : the run of consecutive accepting positions from a0 - result of its last state,
+//                end behind it (the loop leaves at the first non-accepting position behind one);
+//   styFirst   : the same run cut where the result changes (:457-460) - result of a0's state;
+//   start      : the last "left the initial state" position up to and including the position
+//                at which the loop left (the update at :446-451 precedes the tests).
+// Phase A (mabWalkBlock) walks a block without looking; phase B reads the masks: first set bit,
+// first clear bit behind it, and only for styFirst the results along the run.  A lane whose loop
+// has left stops taking blocks, a wave whose lanes all have stops reading: a dense DFA is done
+// within its first block, where k_fixed walked every line to its end.  Requires what
+// k_matchall_blocks requires (absorbing pure dead ends: nothing accepts past one).
+// =========================================================================================
+template <int KIND, int THREADS, int W, bool POS>
+__global__ void __launch_bounds__(THREADS)
+k_style_blocks(DevDfa d, Batch b, int style) {
+  constexpr uint32_t kPos = 64 / W;
+  constexpr uint32_t kPerWord = 4 / W;
+  extern __shared__ __align__(16) uint8_t lds[];
+  const Tab<KIND> tab = stageTab<KIND, THREADS>(d, lds);
+  LaneCtx c{lds, lds + 256, resOf<KIND>(d, lds), d.init, d.leaderNext, d.nPureDead, d.firstAccept,
+            d.leaderLen};
+  uint32_t *stage = reinterpret_cast<uint32_t *>(lds + 512 + ((ldsTableBytes<KIND>(d) + 15) & ~size_t(15)));
+  const uint8_t *stageBytes = reinterpret_cast<const uint8_t *>(stage);
+  const int32_t *ldsRes = reinterpret_cast<const int32_t *>(lds + 512 + ((tableOnlyBytes<KIND>(d) + 15) & ~size_t(15)));
+  const bool tableAt512 = uint32_t(reinterpret_cast<uintptr_t>(lds)) == 0u;
+  const int32_t initRes = d.init >= d.firstAccept ? ldsRes[d.init] : 0;
+  const uint64_t step = uint64_t(gridDim.x) * THREADS;
+  for (uint64_t line = uint64_t(blockIdx.x) * THREADS + threadIdx.x; line < b.n; line += step) {
+    const uint8_t *p;
+    uint64_t n;
+    if (b.offsets) {
+      const uint64_t o = b.offsets[line];
+      p = b.data + o;
+      n = b.offsets[line + 1] - o;
+      n = n >= b.stride ? n - b.stride : 0;  // stride = trailing bytes to drop (ragged)
+    } else {
+      p = b.data + line * b.stride;
+      n = b.stride;
+    }
+    uint32_t s = c.init;
+    // mode 0: no accepting position yet; 1: inside the first run; 2: the loop has left
+    uint32_t mode = 0;
+    int32_t result = n ? 0 : initRes;  // an accepting initial state only counts for empty input
+    int32_t r0 = 0, prevR = 0;
+    uint64_t matchStart = 0, startOut = 0, curEnd = 0;
+    for (uint64_t base = 0; base < n && mode != 2; base += kPos) {
+      const uint64_t wasInit = s == c.init ? 1u : 0u;
+      uint64_t acc = 0, ini = 0;
+      const uint32_t cnt = mabWalkBlock<KIND, THREADS, W>(tab, c, p + base, n - base, s, stage,
+                                                          tableAt512, acc, ini);
+      const uint64_t valid = cnt >= 64 ? ~0ull : (1ull << cnt) - 1;
+      const uint64_t esc = (((ini << 1) | wasInit) & ~ini) & valid;
+      auto resultAt = [&](uint32_t i) -> int32_t {
+        const uint8_t *slot = stageBytes + (((i / kPerWord) * THREADS + threadIdx.x) << 2) +
+                              W * (i % kPerWord);
+        const uint32_t si = W == 1 ? uint32_t(*slot) : uint32_t(*reinterpret_cast<const uint16_t *>(slot));
+        return ldsRes[si];
+      };
+      // the last escape at or below position i of this block, else the one carried in
+      auto startAt = [&](uint32_t i) -> uint64_t {
+        const uint64_t m = esc & ((2ull << i) - 1);
+        return m ? base + 63 - uint32_t(__builtin_clzll(m)) : matchStart;
+      };
+      uint32_t q = 0;  // first position of this block the run still has to look at
+      if (mode == 0 && acc) {
+        const uint32_t a0 = uint32_t(__builtin_ctzll(acc));
+        r0 = prevR = resultAt(a0);
+        curEnd = base + a0 + 1;
+        if (style == kStyInstant) {
+          result = r0;
+          if (POS) startOut = startAt(a0);
+          mode = 2;
+        } else {
+          mode = 1;
+          q = a0 + 1;
+        }
+      }
+      if (mode == 1) {
+        // the run goes on over accepting positions from q; zf = the first one that is not
+        const uint64_t clear = ~acc & valid & (q >= 64 ? 0ull : ~0ull << q);
+        const uint32_t zf = clear ? uint32_t(__builtin_ctzll(clear)) : cnt;
+        uint32_t stop = 0xffffffffu;
+        if (style == kStyFirst) {
+          uint32_t i = q;
+          for (; i < zf; ++i) {
+            if (resultAt(i) != r0) break;  // another result: the loop leaves, keeping the first (:457-460)
+            curEnd = base + i + 1;
+          }
+          if (i < zf) stop = i;
+          else if (zf < cnt) stop = zf;
+          prevR = r0;
+        } else {  // styTangent: the result of the run's last accepting position
+          if (zf > q) {
+            prevR = resultAt(zf - 1);
+            curEnd = base + zf;
+          }
+          if (zf < cnt) stop = zf;
+        }
+        if (stop != 0xffffffffu) {
+          result = prevR;
+          if (POS) startOut = startAt(stop);
+          mode = 2;
+        }
+      }
+      if (esc) matchStart = base + 63 - uint32_t(__builtin_clzll(esc));
+    }
+    if (mode == 1) {  // the line ended inside the run
+      result = prevR;
+      startOut = matchStart;
+    }
+    b.result[line] = result;
+    if (POS) {
+      if (b.start) b.start[line] = result ? startOut : 0;
+      if (b.end) b.end[line] = result ? curEnd : 0;
+    }
   }
 }
 
@@ -2643,6 +2783,46 @@ hipError_t launchMatchAllK(const DevDfa &d, const Batch &b, uint64_t cap, uint64
   return hipGetLastError();
 }
 
+// k_style_blocks: same residency rule as k_matchall_blocks; *taken = false when the DFA / batch
+// does not qualify (the caller goes on to the other kernels)
+template <int KIND>
+hipError_t launchStyleBlocksK(const DevDfa &d, const Batch &b, int style, bool pos,
+                              const LaunchCfg &cfg, hipStream_t stream, bool *taken) {
+  *taken = false;
+  if constexpr (Tab<KIND>::kInLds) {
+    const size_t tab = 512 + ((ldsTableBytes<KIND>(d) + 15) & ~size_t(15));
+    if (!d.deadAbsorbing || !resStaged<KIND>(d) || d.nStates > 65535 ||
+        tab + 512 * 64 + 256 > size_t(160) * 1024)
+      return hipSuccess;
+    auto resident = [&](uint64_t threads) -> uint64_t {
+      uint64_t wgs = (size_t(160) * 1024) / (tab + threads * 64 + 256);
+      if (wgs > 2048 / threads) wgs = 2048 / threads;
+      return wgs;
+    };
+    const bool big = resident(1024) * 1024 >= resident(512) * 512;
+    const int threads = big ? 1024 : 512;
+    const size_t ldsBytes = tab + size_t(threads) * 64;
+    uint64_t blocks = (b.n + threads - 1) / threads;
+    const uint64_t perCu = resident(uint64_t(threads));
+    if (blocks > uint64_t(cfg.numCUs) * perCu) blocks = uint64_t(cfg.numCUs) * perCu;
+#define SB_LAUNCH(T, W, P)                                                                   \
+  do {                                                                                         \
+    hipError_t e2 = setLds(k_style_blocks<KIND, T, W, P>, ldsBytes);                          \
+    if (e2 != hipSuccess) return e2;                                                           \
+    hipLaunchKernelGGL((k_style_blocks<KIND, T, W, P>), dim3(uint32_t(blocks)), dim3(T),      \
+                       ldsBytes, stream, d, b, style);                                         \
+  } while (0)
+#define SB_POS(T, W) do { if (pos) SB_LAUNCH(T, W, true); else SB_LAUNCH(T, W, false); } while (0)
+    if (d.nStates <= 256) { if (big) SB_POS(1024, 1); else SB_POS(512, 1); }
+    else { if (big) SB_POS(1024, 2); else SB_POS(512, 2); }
+#undef SB_POS
+#undef SB_LAUNCH
+    *taken = true;
+    return hipGetLastError();
+  }
+  return hipSuccess;
+}
+
 template <int KIND>
 hipError_t launchVisitsK(const DevDfa &d, const Batch &b, uint32_t *hist, const LaunchCfg &cfg,
                          hipStream_t stream) {
@@ -3230,6 +3410,26 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
     case REDGPU_TAB_LDS_FUSED_U16: return launchEarlyK<REDGPU_TAB_LDS_FUSED_U16>(d, b, verb, style, lead, cfg, stream);
     case REDGPU_TAB_LDS_CLASS_U16: return launchEarlyK<REDGPU_TAB_LDS_CLASS_U16>(d, b, verb, style, lead, cfg, stream);
     default: return launchEarlyK<REDGPU_TAB_LDS_SPARSE>(d, b, verb, style, lead, cfg, stream);
+    }
+  }
+
+  // check / match with an early-exit style, no leader, table in LDS: the block kernel
+  if ((verb == kCheck || verb == kMatch) && !lead && !cfg.forceGeneric && !d.earlyDeath &&
+      (style == kStyInstant || style == kStyFirst || style == kStyTangent) && b.n >= 4096) {
+    bool taken = false;
+    const bool pos = verb == kMatch && (b.start || b.end);
+    hipError_t se = hipSuccess;
+    switch (d.tableKind) {
+    case REDGPU_TAB_LDS_FUSED_U8: se = launchStyleBlocksK<REDGPU_TAB_LDS_FUSED_U8>(d, b, style, pos, cfg, stream, &taken); break;
+    case REDGPU_TAB_LDS_FUSED_U16: se = launchStyleBlocksK<REDGPU_TAB_LDS_FUSED_U16>(d, b, style, pos, cfg, stream, &taken); break;
+    case REDGPU_TAB_LDS_CLASS_U16: se = launchStyleBlocksK<REDGPU_TAB_LDS_CLASS_U16>(d, b, style, pos, cfg, stream, &taken); break;
+    case REDGPU_TAB_LDS_SPARSE: se = launchStyleBlocksK<REDGPU_TAB_LDS_SPARSE>(d, b, style, pos, cfg, stream, &taken); break;
+    default: break;
+    }
+    if (se != hipSuccess) return se;
+    if (taken) {
+      *kernelName = verb == kMatch ? "k_style_blocks<match>" : "k_style_blocks<check>";
+      return hipSuccess;
     }
   }
 

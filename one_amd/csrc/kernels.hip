@@ -1882,12 +1882,13 @@ __device__ __forceinline__ void mabBook(uint32_t s, uint32_t &accR, uint32_t &in
 //   stage     : the states themselves, W bytes each, lane-interleaved in LDS
 //               (word w of lane t at stage[w * THREADS + t]: no bank conflicts);
 //   s         : the state after the last position walked.
+// `safe` = bytes that may be read from p on (to the end of the batch's buffer).
 // Returns the number of positions walked (kPos, or all that was left of the line).
 template <int KIND, int THREADS, int W>
 __device__ __forceinline__ uint32_t mabWalkBlock(const Tab<KIND> &tab, const LaneCtx &c,
-                                                 const uint8_t *p, uint64_t rem, uint32_t &s,
-                                                 uint32_t *stage, bool tableAt512, uint64_t &acc,
-                                                 uint64_t &ini) {
+                                                 const uint8_t *p, uint64_t rem, uint64_t safe,
+                                                 uint32_t &s, uint32_t *stage, bool tableAt512,
+                                                 uint64_t &acc, uint64_t &ini) {
   constexpr uint32_t kPos = 64 / W;
   constexpr uint32_t kPerWord = 4 / W;
   const uint32_t nq = rem >= kPos ? kPos / 16 : uint32_t(rem >> 4);  // whole 16-byte pieces
@@ -1939,7 +1940,28 @@ __device__ __forceinline__ uint32_t mabWalkBlock(const Tab<KIND> &tab, const Lan
     }
   }
   uint32_t cnt = 16 * nq;
-  if (cnt < kPos && cnt < rem) {  // the last < 16 bytes of the line
+  if (cnt < kPos && cnt < rem && safe >= uint64_t(cnt) + 16) {
+    // the last < 16 bytes of the line, from one more 16-byte request (it reaches into the next
+    // line, never past the buffer: `safe`) - a byte load per step is a memory round trip per step
+    const uint32_t left = uint32_t(rem) - cnt;
+    const uint4 v = *reinterpret_cast<const uint4 *>(p + cnt);
+    const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (uint32_t k = 0; k < 15; ++k) {
+      if (k < left) {
+        const uint32_t pos = cnt + k;
+        s = tab.next(s, (words[k >> 2] >> (8 * (k & 3))) & 0xffu);
+        acc |= uint64_t(s >= c.firstAccept) << pos;
+        ini |= uint64_t(s == c.init) << pos;
+        uint8_t *slot = reinterpret_cast<uint8_t *>(stage) +
+                        (((pos / kPerWord) * THREADS + threadIdx.x) << 2) + W * (pos % kPerWord);
+        if (W == 1) *slot = uint8_t(s);
+        else *reinterpret_cast<uint16_t *>(slot) = uint16_t(s);
+      }
+    }
+    cnt += left;
+  }
+  if (cnt < kPos && cnt < rem) {  // ... or byte by byte at the very end of the buffer
     const uint32_t last = uint32_t(rem);  // < kPos here
     for (; cnt < last; ++cnt) {
       s = tab.next(s, uint32_t(p[cnt]));
@@ -1988,6 +2010,7 @@ k_matchall_blocks(DevDfa d, Batch b, uint64_t cap, uint64_t *counts, int lead) {
   const int32_t *ldsRes = reinterpret_cast<const int32_t *>(lds + 512 + ((tableOnlyBytes<KIND>(d) + 15) & ~size_t(15)));
   // the asm walk addresses the table at LDS offset 512: true while the kernel has no static LDS
   const bool tableAt512 = uint32_t(reinterpret_cast<uintptr_t>(lds)) == 0u;
+  const uint8_t *bufEnd = b.data + (b.offsets ? b.offsets[b.n] : b.n * b.stride);
   const uint64_t step = uint64_t(gridDim.x) * THREADS;
   for (uint64_t line = uint64_t(blockIdx.x) * THREADS + threadIdx.x; line < b.n; line += step) {
     const uint8_t *p;
@@ -2012,7 +2035,8 @@ k_matchall_blocks(DevDfa d, Batch b, uint64_t cap, uint64_t *counts, int lead) {
       const uint64_t wasInit = s == c.init ? 1u : 0u;
       uint64_t acc = 0, ini = 0;
       // ---- A: the walk (mabWalkBlock) ------------------------------------------------------------
-      const uint32_t cnt = mabWalkBlock<KIND, THREADS, W>(tab, c, p + base, n - base, s, stage,
+      const uint32_t cnt = mabWalkBlock<KIND, THREADS, W>(tab, c, p + base, n - base,
+                                                          bufEnd - (p + base), s, stage,
                                                           tableAt512, acc, ini);
       // ---- B: the accepting positions ----------------------------------------------------------
       const uint64_t valid = cnt >= 64 ? ~0ull : (1ull << cnt) - 1;
@@ -2094,6 +2118,7 @@ k_style_blocks(DevDfa d, Batch b, int style) {
   const uint8_t *stageBytes = reinterpret_cast<const uint8_t *>(stage);
   const int32_t *ldsRes = reinterpret_cast<const int32_t *>(lds + 512 + ((tableOnlyBytes<KIND>(d) + 15) & ~size_t(15)));
   const bool tableAt512 = uint32_t(reinterpret_cast<uintptr_t>(lds)) == 0u;
+  const uint8_t *bufEnd = b.data + (b.offsets ? b.offsets[b.n] : b.n * b.stride);
   const int32_t initRes = d.init >= d.firstAccept ? ldsRes[d.init] : 0;
   const uint64_t step = uint64_t(gridDim.x) * THREADS;
   for (uint64_t line = uint64_t(blockIdx.x) * THREADS + threadIdx.x; line < b.n; line += step) {
@@ -2117,7 +2142,8 @@ k_style_blocks(DevDfa d, Batch b, int style) {
     for (uint64_t base = 0; base < n && mode != 2; base += kPos) {
       const uint64_t wasInit = s == c.init ? 1u : 0u;
       uint64_t acc = 0, ini = 0;
-      const uint32_t cnt = mabWalkBlock<KIND, THREADS, W>(tab, c, p + base, n - base, s, stage,
+      const uint32_t cnt = mabWalkBlock<KIND, THREADS, W>(tab, c, p + base, n - base,
+                                                          bufEnd - (p + base), s, stage,
                                                           tableAt512, acc, ini);
       const uint64_t valid = cnt >= 64 ? ~0ull : (1ull << cnt) - 1;
       const uint64_t esc = (((ini << 1) | wasInit) & ~ini) & valid;
@@ -2132,6 +2158,18 @@ k_style_blocks(DevDfa d, Batch b, int style) {
         const uint64_t m = esc & ((2ull << i) - 1);
         return m ? base + 63 - uint32_t(__builtin_clzll(m)) : matchStart;
       };
+      if (style == kStyLast || style == kStyFull) {
+        // the whole-line styles (fixed strides the streaming kernels do not take): styLast wants the
+        // LAST accepting position - the top bit of the mask, its state read back while the block is
+        // still staged; styFull only the final state
+        if (style == kStyLast && acc) {
+          const uint32_t i = 63 - uint32_t(__builtin_clzll(acc));
+          prevR = resultAt(i);
+          curEnd = base + i + 1;
+        }
+        if (esc) matchStart = base + 63 - uint32_t(__builtin_clzll(esc));
+        continue;
+      }
       uint32_t q = 0;  // first position of this block the run still has to look at
       if (mode == 0 && acc) {
         const uint32_t a0 = uint32_t(__builtin_ctzll(acc));
@@ -2175,7 +2213,14 @@ k_style_blocks(DevDfa d, Batch b, int style) {
       }
       if (esc) matchStart = base + 63 - uint32_t(__builtin_clzll(esc));
     }
-    if (mode == 1) {  // the line ended inside the run
+    if (style == kStyLast) {
+      if (n) result = prevR;
+      startOut = matchStart;
+    } else if (style == kStyFull) {
+      if (n) result = s >= d.firstAccept ? ldsRes[s] : 0;
+      startOut = matchStart;
+      curEnd = n;  // end is the line length when the final state accepts (Matcher.h:463)
+    } else if (mode == 1) {  // the line ended inside the run
       result = prevR;
       startOut = matchStart;
     }
@@ -3414,8 +3459,12 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
   }
 
   // check / match with an early-exit style, no leader, table in LDS: the block kernel
+  // ... and the whole-line styles on a fixed stride that is not a multiple of 64 (100-byte
+  // records, 250-byte lines: k_fixed / k_generic gave those a lane each at 1-1.7 TB/s)
+  const bool oddStride = !b.offsets && b.stride >= 32 && b.stride % 64 != 0;
   if ((verb == kCheck || verb == kMatch) && !lead && !cfg.forceGeneric && !d.earlyDeath &&
-      (style == kStyInstant || style == kStyFirst || style == kStyTangent) && b.n >= 4096) {
+      (style == kStyInstant || style == kStyFirst || style == kStyTangent ||
+       ((style == kStyLast || style == kStyFull) && oddStride)) && b.n >= 4096) {
     bool taken = false;
     const bool pos = verb == kMatch && (b.start || b.end);
     hipError_t se = hipSuccess;

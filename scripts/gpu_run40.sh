@@ -5,5 +5,5 @@ timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_boun
 tail -1 gpurun_out/r2_tmp.log
 timeout -k 10 500 python3 scripts/fuzz_gpu.py 500 101 > gpurun_out/r2_fuzz.log 2>&1 || { tail -30 gpurun_out/r2_fuzz.log; exit 1; }
 tail -1 gpurun_out/r2_fuzz.log | cut -c1-400
-export VERBS=check,match,search
-for d in syn256 uri; do echo "== $d"; timeout -k 10 200 python3 scripts/bench_styles.py $d 2>&1 | grep -v amdgpu | grep "Instant\|First\|Tangent"; done
+export VERBS=match
+timeout -k 10 250 python3 scripts/bench_strides.py syn256 2>&1 | grep -v amdgpu

@@ -93,11 +93,35 @@ def _fixed_inputs(name, n, stride, seed):
     if name == "syn256":
         return W.fixed_lines(n, stride, seed, alphabet=False)
     plant = {"uri": W.URI_PLANT, "err": b"error", "num3": b"123abcd ", "newyork": b"New York",
-             "aab": b"aab", "dotstar_err": b"an error"}[name]
+             "aab": b"aab", "dotstar_err": b"an error", "uri_user": W.URI_PLANT}[name]
     buf = W.fixed_lines(n, stride, seed, plant=plant, plant_every=3, plant_at=min(7, stride - 8))
     v = buf.reshape(n, stride)
     v[1::5, :len(plant[:stride])] = np.frombuffer(plant[:stride], dtype=np.uint8)  # at line start
     return buf
+
+
+@pytest.mark.parametrize("stride,n", [(48, 5000), (80, 4096), (100, 6001), (250, 4500), (1000, 4100),
+                                      (33, 7000), (63, 4097)])
+@pytest.mark.parametrize("name", ["syn256", "uri", "newyork", "dotstar_err", "uri_user"])
+def test_odd_fixed_strides_block_kernel_vs_oracle(name, stride, n):
+    """k_style_blocks on fixed strides that are not multiples of 64 (the streaming kernels want
+    whole 64-byte blocks): every style of check and match, with and without start, against the
+    oracle; the same batch through the per-lane kernels (force_generic) must agree as well."""
+    blob = load_dfa(name)
+    exe, gen, cpu = one_amd.Executable(blob), one_amd.Executable(blob, force_generic=True), O.CpuOracle(blob)
+    data = _fixed_inputs(name, n, stride, seed=3 * stride + n)
+    for si in range(1, 6):
+        er, es, ee = cpu.batch("match", si, 0, data, stride=stride, n=n, threads=4)
+        r, s, e = one_amd.match_batch(exe, data, si, 0, stride=stride, n=n)
+        assert one_amd.last_kernel().startswith("k_style_blocks"), (one_amd.last_kernel(), si)
+        assert np.array_equal(r, er), (name, "match", si)
+        assert np.array_equal(s, es) and np.array_equal(e, ee), (name, "match", si)
+        r2, _, e2 = one_amd.match_batch(exe, data, si, 0, stride=stride, n=n, want_start=False)
+        assert np.array_equal(r2, er) and np.array_equal(e2, ee)
+        rg, sg, eg = one_amd.match_batch(gen, data, si, 0, stride=stride, n=n)
+        assert np.array_equal(rg, er) and np.array_equal(sg, es) and np.array_equal(eg, ee)
+        cr = cpu.batch("check", si, 0, data, stride=stride, n=n, threads=4)[0]
+        assert np.array_equal(one_amd.check_batch(exe, data, si, 0, stride=stride, n=n), cr), (name, si)
 
 
 @pytest.mark.parametrize("stride,n", [(64, 5000), (16, 1500), (4096, 300), (48, 2049),

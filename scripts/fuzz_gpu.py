@@ -16,6 +16,8 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 HOT_BIAS = len(sys.argv) > 3 and sys.argv[3] in ("hot", "cls")  # big DFAs, block-multiple strides
 CLS_BIAS = len(sys.argv) > 3 and sys.argv[3] == "cls"           # ... of the class-table size
 LISTS = len(sys.argv) > 3 and sys.argv[3] == "lists"            # only the record-list verbs
+BLOCKS = len(sys.argv) > 3 and sys.argv[3] == "blocks"          # >= 4096 lines, check / match /
+                                                                # match_all: the block kernels
 rng = np.random.default_rng(seed)
 ALPHA = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz0123456789 ./:-_=&?%@[]", dtype=np.uint8)
 
@@ -52,6 +54,17 @@ def make_dfa():
 
 def make_lines():
     total_cap = 600_000
+    if BLOCKS:
+        if rng.random() < 0.6:
+            L = int(rng.choice([32, 33, 48, 63, 64, 65, 80, 100, 127, 129]))
+            n = int(rng.integers(4096, 6000))
+            return dict(stride=L, n=n), n * L
+        n = int(rng.choice([4096, 5000, 9000]))
+        lens = rng.integers(0, 140, n) if rng.random() < 0.7 else rng.geometric(1 / 30, n) - 1
+        lens = np.minimum(lens, 300).astype(np.int64)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(lens)
+        return dict(offsets=off), int(off[-1])
     if rng.random() < 0.5:
         L = int(rng.choice([64, 128, 192, 256, 1024, 4096] if HOT_BIAS else
                            [0, 1, 15, 16, 17, 48, 63, 64, 65, 128, 192, 256, 1000, 4096]))
@@ -122,9 +135,11 @@ for case in range(cases):
     desc = (case, name, {k: (v if not hasattr(v, "shape") else "offsets[%d]" % (len(v) - 1)) for k, v in shape.items()}, flags, exe.info["table_kind"])
     verbs = (["match", "check", "advance", "match", "check"] if HOT_BIAS else
              ["match", "check", "scan", "search", "advance", "match_all", "collect", "replace"])
+    if BLOCKS:
+        verbs = ["match", "check", "match_all", "match", "check"]
     if LISTS:
         verbs = ["match_all", "collect", "match_all"]
-    for verb in (rng.choice(verbs, 3) if HOT_BIAS or LISTS else rng.choice(verbs, 3, replace=False)):
+    for verb in (rng.choice(verbs, 3) if HOT_BIAS or LISTS or BLOCKS else rng.choice(verbs, 3, replace=False)):
         sty = int(rng.choice([4, 5, 4, 5, 1, 2, 3])) if HOT_BIAS else int(rng.integers(1, 6))
         lead = int(rng.integers(0, 2))
         kw = dict(shape)

@@ -1898,7 +1898,16 @@ __device__ __forceinline__ uint32_t mabWalkBlock(const Tab<KIND> &tab, const Lan
     piece[q] = q < nq ? *reinterpret_cast<const uint4 *>(p + 16 * q) : make_uint4(0, 0, 0, 0);
   bool walked = false;
   if constexpr (KIND == REDGPU_TAB_LDS_FUSED_U8 && W == 1) {
-    if (nq == kPos / 16 && tableAt512) {
+    // a line's LAST block, shorter than 64 bytes, takes the same 64 straight-line steps when the
+    // buffer has the bytes (they belong to the next line): the masks are cut to the line's
+    // positions afterwards and the state is read back from the staged ones
+    // (from 44 bytes up: 64 steps of 7 instructions against `rem` steps of 13)
+    const bool whole = nq < kPos / 16 && rem >= 44 && safe >= 64;
+    if (whole && tableAt512) {
+#pragma unroll
+      for (uint32_t q = 0; q < kPos / 16; ++q) piece[q] = *reinterpret_cast<const uint4 *>(p + 16 * q);
+    }
+    if ((nq == kPos / 16 || whole) && tableAt512) {
       // a whole block over the fused table: mabStep, masks first-position-high, two halves
       uint32_t aR[2] = {0, 0}, iR[2] = {0, 0}, packed = 0;
 #pragma unroll
@@ -1918,6 +1927,15 @@ __device__ __forceinline__ uint32_t mabWalkBlock(const Tab<KIND> &tab, const Lan
       acc = (uint64_t(__builtin_bitreverse32(aR[1])) << 32) | __builtin_bitreverse32(aR[0]);
       ini = (uint64_t(__builtin_bitreverse32(iR[1])) << 32) | __builtin_bitreverse32(iR[0]);
       walked = true;
+      if (rem < kPos) {  // cut back to the line
+        const uint32_t cntv = uint32_t(rem);
+        const uint64_t valid = (1ull << cntv) - 1;
+        acc &= valid;
+        ini &= valid;
+        s = reinterpret_cast<const uint8_t *>(stage)[(((cntv - 1) / 4) * THREADS + threadIdx.x) * 4 +
+                                                     (cntv - 1) % 4];
+        return cntv;
+      }
     }
   }
 #pragma unroll

@@ -280,3 +280,45 @@ def test_gather_outcomes_native_records_over_rccl_one_rank(tmp_path):
                     assert gs is None
     finally:
         dist.destroy_process_group()
+
+
+def test_dev_entry_point_captured_in_a_hip_graph():
+    """The stream-ordered `_dev` entry points on the fixed-stride path neither synchronise nor
+    allocate, so a caller may capture them (bench.py's graph_replay leg): four launches
+    over two batches captured once, replayed twice, outputs against the oracle."""
+    import torch
+    blob = load_dfa("syn256")
+    cpu = O.CpuOracle(blob)
+    exe = one_amd.Executable(blob)
+    n, L = 20000, 64
+    hosts = [W.fixed_lines(n, L, 70 + k, alphabet=False) for k in range(2)]
+    bufs = [torch.from_numpy(h).cuda() for h in hosts]
+    outs = [(torch.zeros(n, dtype=torch.int32, device="cuda"), torch.zeros(n, dtype=torch.int64, device="cuda"),
+             torch.zeros(n, dtype=torch.int64, device="cuda")) for _ in range(2)]
+    fn = _lib.lib().redgpu_match_batch_dev
+
+    def call(k, stream):
+        r, s, e = outs[k]
+        return fn(exe._h, 4, 0, bufs[k].data_ptr(), None, L, n, r.data_ptr(), s.data_ptr(), e.data_ptr(), stream)
+
+    gs = torch.cuda.Stream()
+    with torch.cuda.stream(gs):
+        for k in range(2):
+            assert call(k, gs.cuda_stream) == 0  # warm: every lazy first-use cost happens before the capture
+    gs.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=gs):
+        for k in (0, 1, 0, 1):
+            assert call(k, torch.cuda.current_stream().cuda_stream) == 0
+    for o in outs:
+        for t in o:
+            t.zero_()
+    graph.replay()
+    graph.replay()
+    torch.cuda.synchronize()
+    for k in range(2):
+        er, es, ee = cpu.batch("match", 4, 0, hosts[k], stride=L, n=n, threads=4)
+        r, s, e = outs[k]
+        assert np.array_equal(r.cpu().numpy(), er)
+        assert np.array_equal(s.cpu().numpy().astype(np.uint64), es.astype(np.uint64))
+        assert np.array_equal(e.cpu().numpy().astype(np.uint64), ee.astype(np.uint64))

@@ -63,10 +63,15 @@ def parse_args():
                          "redgpu_dfa_tune on a 4 MiB sample of the input, outside the timed region)")
     ap.add_argument("--no-calibration", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--streams", type=int, default=None,
-                    help="HIP streams the steps are issued on round-robin (independent batches "
-                         "overlap: one step's ramp-up hides under the previous step's tail); "
-                         "default 3 for config 1, else 1")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the steps are issued on round-robin (1 = one stream; more "
+                         "is a diagnostic, not the default: overlap of consecutive batches is the "
+                         "library's job, see --per-call)")
+    ap.add_argument("--per-call", type=int, default=None,
+                    help="steps handed to the library per call of redgpu_match_batches_dev (the "
+                         "caller's loop over its inputs, tools/bench.cpp:60-71, given to the "
+                         "library whole); default min(steps, 32) for config 1, 1 elsewhere. "
+                         "1 = one redgpu_match_batch_dev call per step")
     return ap.parse_args()
 
 
@@ -110,6 +115,7 @@ class Workload:
             self.nbuf = args.buffers or 2
             self.label = "configs[4]"
         self._build_inputs()
+        self._expected = {}
         self.tuned = None
         if not args.no_tune and self.info["table_kind"] == 6 and not self.ragged:
             # REDGPU_TAB_HOT_ROWS: re-rank the LDS-resident rows by a sample of the input (outside
@@ -161,7 +167,7 @@ class Workload:
             self.bufs.append(torch.from_numpy(data).cuda())
             self.offsets_dev = torch.from_numpy(offsets.astype("int64")).cuda()
             self.in_bytes = int(offsets[-1])
-        nout = max(3, 2 * (a.streams or 1))
+        nout = max(3, 2 * (a.streams or 1), a.per_call or 1)
         self.outs = [(torch.empty(n, dtype=torch.int32, device="cuda"),
                       torch.empty(n, dtype=torch.int64, device="cuda") if self.want_start else None,
                       torch.empty(n, dtype=torch.int64, device="cuda")) for _ in range(nout)]
@@ -197,8 +203,10 @@ class Workload:
 
         c = self.args.config
         if c == 1:
-            er, es, ee = cpu.batch("match", "last", self.lead, self.hosts[b], stride=self.L,
-                                   n=self.n, threads=threads)
+            if b not in self._expected:  # one oracle pass per input buffer, however many outputs
+                self._expected[b] = cpu.batch("match", "last", self.lead, self.hosts[b],
+                                              stride=self.L, n=self.n, threads=threads)
+            er, es, ee = self._expected[b]
             return same(None, er, es, ee), int((er > 0).sum())
         if c == 3:
             data, offsets = self.hosts[0]
@@ -222,7 +230,8 @@ class Workload:
         return same(idx, er, es, ee), int((er > 0).sum())
 
     def verify_note(self):
-        return {1: "every line of the last output of every stream vs the CPU oracle",
+        return {1: "every line of every batch of the last call (per-call mode) / of the last output of "
+                   "every stream vs the CPU oracle",
                 2: "1024 lines spread over the last output of every stream vs the CPU oracle",
                 3: "first and last 65,536 lines of the last output vs the CPU oracle",
                 4: "64 inputs spread over the last output of every stream vs the CPU oracle"}[
@@ -333,24 +342,38 @@ def main():
 
     if args.config is None:
         args.config = 2 if multi else 1
-    if args.streams is None:
-        args.streams = 3 if (args.config == 1 and not multi) else 1
     if args.steps is None:
         args.steps = {1: 300, 2: 20, 3: 40, 4: 5}[args.config]
     if args.warmup is None:
         args.warmup = {1: 30, 2: 3, 3: 5, 4: 1}[args.config]
+    if args.per_call is None:
+        args.per_call = min(max(1, args.steps), 32) if (args.config == 1 and not multi) else 1
+    if multi or args.streams > 1:
+        args.per_call = 1
+    per_call = args.per_call
 
     import oracle  # checker and CPU baseline only - never inside a timed region
     wl = Workload(args, rank, torch, W, one_amd, oracle)
     info, n = wl.info, wl.n
 
+    import ctypes as C
     fn = _lib.lib().redgpu_match_batch_dev
+    fn_many = _lib.lib().redgpu_match_batches_dev
     cur_stream = torch.cuda.current_stream().cuda_stream
     streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else None
     period = len(wl.bufs) * len(wl.outs) * max(1, args.streams)
     calls = [wl.call_tuple(i, streams[i % len(streams)].cuda_stream if streams else cur_stream)
              for i in range(period)]
+    # the same steps as redgpu_batch descriptors: step i = descs[i % period]; a call of the
+    # multi-batch entry point takes a window of consecutive steps (the array is doubled so that a
+    # window never wraps)
+    descs = (_lib.BatchDesc * (2 * period))()
+    for i in range(2 * period):
+        c = calls[i % period]
+        descs[i] = _lib.BatchDesc(c[3], c[4], c[5], c[6], c[7], c[8], c[9])
+    dsz = C.sizeof(_lib.BatchDesc)
     last_on_stream = {}
+    last_call = []
 
     def step(i):
         rc = fn(*calls[i % period])
@@ -358,6 +381,38 @@ def main():
             raise RuntimeError(_lib.lib().redgpu_last_error().decode())
         last_on_stream[i % max(1, args.streams)] = (i % len(wl.bufs), i % len(wl.outs))
         return wl.outs[i % len(wl.outs)]
+
+    wins = {}
+
+    def window(i, cnt):
+        """descriptors of steps i .. i + cnt - 1 (built once: outside the timed region)"""
+        key = (i % period, cnt)
+        if key not in wins:
+            wins[key] = (_lib.BatchDesc * cnt).from_buffer(descs, key[0] * dsz)
+        return wins[key]
+
+    def steps_call(i, cnt):
+        """steps i .. i + cnt - 1 in ONE call of redgpu_match_batches_dev on the current stream"""
+        rc = fn_many(wl.exe._h, wl.style, wl.lead, window(i, cnt), cnt, cur_stream)
+        if rc != 0:
+            raise RuntimeError(_lib.lib().redgpu_last_error().decode())
+        last_call[:] = [((i + k) % len(wl.bufs), (i + k) % len(wl.outs)) for k in range(cnt)]
+
+    def run_steps(count):
+        """`count` steps, the way this run issues them; returns the last step's outputs"""
+        if per_call <= 1:
+            o = None
+            for i in range(count):
+                o = step(i)
+                if gather:
+                    gather.push(o)
+            return o
+        i = 0
+        while i < count:
+            cnt = min(per_call, count - i)
+            steps_call(i, cnt)
+            i += cnt
+        return wl.outs[(count - 1) % len(wl.outs)]
 
     # ---- multi-GPU: every step's Outcomes gathered to rank 0 (compact records, pipelined) -------
     gather = None
@@ -385,33 +440,43 @@ def main():
             solo = k * wl.in_bytes / (time.perf_counter() - t0) / 1e9
         dist.barrier()
 
-    for i in range(args.warmup):
-        o = step(i)
-        if gather:
-            gather.push(o)
+    if per_call > 1:  # the timed loop's descriptor windows, before any clock starts
+        for i in range(0, max(args.steps, args.warmup), per_call):
+            for count in (args.steps, args.warmup):
+                if i < count:
+                    window(i, min(per_call, count - i))
+    # (the two events exist - torch creates the HIP event at its first record() - before any clock
+    # starts: creating them inside the timed region cost ~50 us of a 0.4 ms region)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    run_steps(args.warmup)
+    ev1.record()
     if streams is not None:
         for st in streams:
             torch.cuda.current_stream().wait_stream(st)
     if gather:
         gather.flush()
     torch.cuda.synchronize()
+    ev1.query()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
 
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for i in range(args.steps):
-        o = step(i)
-        if gather:
-            gather.push(o)
+    run_steps(args.steps)
     if streams is not None:
         for st in streams:
             torch.cuda.current_stream().wait_stream(st)
     ev1.record()
+    t_issued = time.perf_counter()
     if gather:
         gather.flush()  # the gathers still in flight: inside the timed region
+    else:
+        # poll the closing event instead of sleeping in the synchronize below: a blocking wait
+        # returns tens of microseconds after the GPU is done, which on a 0.35 ms region is not noise
+        while not ev1.query():
+            pass
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -434,6 +499,11 @@ def main():
         bit_exact = bit_exact and ok
         matches += hits
         checked.append({"stream": sidx, "buffer": b, "ok": ok})
+    for k, (b, o) in enumerate(last_call):  # every batch of the last multi-batch call
+        ok, hits = wl.verify(b, o)
+        bit_exact = bit_exact and ok
+        matches += hits
+        checked.append({"batch_of_last_call": k, "buffer": b, "ok": ok})
     if dist:
         t = torch.tensor([1 if bit_exact else 0], dtype=torch.int64,
                          device="cuda" if backend == "nccl" else "cpu")
@@ -467,7 +537,7 @@ def main():
     # ---- dominant kernel's average launch duration: HIP events on its launch stream --------------
     # One stream, launches back to back, one event before the first and one after the last:
     # elapsed / launches = the kernel's duration plus the ~1.5 us gap between dependent launches -
-    # what `rocprofv3 --kernel-trace --stats` reports for the same command with --streams 1.
+    # what `rocprofv3 --kernel-trace --stats` reports for the same command.
     torch.cuda.synchronize()
     nk = max(5, min(args.steps, 200))
     single = [c[:-1] + (cur_stream,) for c in calls]
@@ -479,7 +549,25 @@ def main():
         fn(*single[i % period])
     k1.record()
     torch.cuda.synchronize()
-    kernel_ms = k0.elapsed_time(k1) / nk
+    kernel_ms_single = k0.elapsed_time(k1) / nk
+    single_kernel_name = one_amd.last_kernel()
+    kernel_ms = kernel_ms_single
+    launches_timed = nk
+    if per_call > 1:
+        # the timed path's own launch: per_call batches per launch of k_stream_multi
+        cnt = min(per_call, max(1, args.steps))
+        reps = max(3, min(20, 200 // cnt))
+        for r in range(2):
+            steps_call(r * cnt, cnt)
+        k0.record()
+        for r in range(reps):
+            steps_call(r * cnt, cnt)
+        k1.record()
+        torch.cuda.synchronize()
+        kernel_ms = k0.elapsed_time(k1) / reps
+        launches_timed = reps
+        kernel_name = one_amd.last_kernel()
+    batches_per_launch = min(per_call, max(1, args.steps)) if per_call > 1 else 1
 
     # ---- calibrations, same session -------------------------------------------------
     calib = {}
@@ -631,58 +719,66 @@ def main():
     # ---- the line ---------------------------------------------------------------------------------
     value = world * args.steps * wl.in_bytes / elapsed / 1e9
     l2_bound = info["table_kind"] in (4, 5)  # REDGPU_TAB_GLOBAL_*: one L2 gather per byte
-    algo_bytes = walked if walked is not None else wl.in_bytes
-    # the launch's duration: the back-to-back loop above counts the gap between dependent launches
-    # with every kernel; the same launches replayed from a HIP graph (calibration c5) do not pay
-    # the host's part of it and sit closer to what rocprofv3 reports per kernel - the smaller of
-    # the two is taken, both are stated
-    kernel_ms_loop = kernel_ms
-    kernel_ms_graph = None
-    if calib.get("graph_replay_GBps"):
-        kernel_ms_graph = wl.in_bytes / (calib["graph_replay_GBps"] * 1e9) * 1e3
-        kernel_ms = min(kernel_ms, kernel_ms_graph)
+    algo_bytes = (walked if walked is not None else wl.in_bytes) * batches_per_launch
+    # kernel_ms = the measured back-to-back loop of the timed path's own launches (it counts the
+    # ~1.5 us gap between dependent launches with every kernel); a HIP-graph replay of the
+    # single-batch launches is reported beside it (graph_replay_GBps), never folded in
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_config%d_%s.json" % (args.config, wl.dfa_name))
-    if world == 1 and os.path.exists(pmc_path):
-        pj = json.load(open(pmc_path))
-        traffic = pj.get("hbm_traffic_bytes_per_launch")
-        traffic_src = ("%s: separate rocprofv3 --pmc passes of this command (FETCH_SIZE doubled per "
-                       "the gfx950 note + WRITE_SIZE), NOT measured by this run" %
-                       os.path.relpath(pmc_path, ROOT))
+    for tag in ("r03", "r02"):
+        pmc_path = os.path.join(ROOT, "profiles", "%s_pmc_config%d_%s.json" % (tag, args.config, wl.dfa_name))
+        if world == 1 and os.path.exists(pmc_path):
+            pj = json.load(open(pmc_path))
+            if pj.get("batches_per_launch", 1) != batches_per_launch:
+                continue
+            traffic = pj.get("hbm_traffic_bytes_per_launch")
+            traffic_src = ("%s: separate rocprofv3 --pmc passes of this command (FETCH_SIZE doubled "
+                           "per the gfx950 note + WRITE_SIZE), NOT measured by this run" %
+                           os.path.relpath(pmc_path, ROOT))
+            break
+    peak = L2_PEAK_GLOOKUPS if l2_bound else HBM_PEAK_GBS
     roofline = {
         "bound": "l2-gather" if l2_bound else "hbm",
         "achieved": round(achieved, 1),
-        "peak": L2_PEAK_GLOOKUPS if l2_bound else HBM_PEAK_GBS,
+        "peak": peak,
         "unit": "Glookups/s" if l2_bound else "GB/s",
-        "frac": round(achieved / (L2_PEAK_GLOOKUPS if l2_bound else HBM_PEAK_GBS), 4),
+        "frac": round(achieved / peak, 4),
         "traffic": traffic,
         "kernel": kernel_name,
+        "batches_per_launch": batches_per_launch,
         "algorithmic_bytes_per_launch": algo_bytes,
-        "input_bytes_per_launch": wl.in_bytes,
-        "output_bytes_per_launch": wl.out_bytes - (8 * n if wl.ragged else 0),
+        "input_bytes_per_launch": wl.in_bytes * batches_per_launch,
+        "output_bytes_per_launch": (wl.out_bytes - (8 * n if wl.ragged else 0)) * batches_per_launch,
         "kernel_ms": round(kernel_ms, 5),
-        "kernel_ms_how": ("HIP events around %d back-to-back launches on one stream (includes the "
-                          "~1.5 us dependent-launch gap): %.5f ms" % (nk, kernel_ms_loop)) +
-                         ("; the same launches replayed from a HIP graph: %.5f ms; the smaller is "
-                          "kernel_ms" % kernel_ms_graph if kernel_ms_graph else ""),
+        "kernel_ms_how": "HIP events around %d back-to-back launches of %s on one stream (includes "
+                         "the ~1.5 us dependent-launch gap)" % (launches_timed, kernel_name),
         "timed_region_ms_per_step": round(region_ms / args.steps, 5),
+        "timed_region_host_issue_ms": round((t_issued - t0) * 1e3, 5),
     }
+    if batches_per_launch > 1:
+        # the same workload one batch per launch (redgpu_match_batch_dev per step): what a caller
+        # that cannot hand over several batches at once gets
+        a1 = (walked if walked is not None else wl.in_bytes) / (kernel_ms_single * 1e-3) / 1e9
+        roofline["single_batch_launch"] = {
+            "kernel": single_kernel_name, "kernel_ms": round(kernel_ms_single, 5),
+            "achieved": round(a1, 1), "frac": round(a1 / peak, 4),
+            "how": "HIP events around %d back-to-back single-batch launches on one stream" % nk}
     # "also report total-traffic GB/s = sum(L + out [+ 8]) / t" - what the launch must
     # move at the least: the lines, their offsets (ragged) and the Outcome fields it writes
-    roofline["total_traffic_GBps"] = round((wl.in_bytes + wl.out_bytes) / (kernel_ms * 1e-3) / 1e9, 1)
+    roofline["total_traffic_GBps"] = round((wl.in_bytes + wl.out_bytes) * batches_per_launch /
+                                           (kernel_ms * 1e-3) / 1e9, 1)
     roofline["total_traffic_frac"] = round(roofline["total_traffic_GBps"] / HBM_PEAK_GBS, 4)
     if traffic_src:
         roofline["traffic_source"] = traffic_src
     if l2_bound:
-        roofline["hbm_frac"] = round(wl.in_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        roofline["hbm_frac"] = round(wl.in_bytes * batches_per_launch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         roofline["bound_note"] = ("one dependent gather of the 2 MiB class table per input byte; it "
                                   "lives in L2 (4 MiB per XCD), whose request rate - 34.5 TB/s / "
                                   "128 B - caps any one-lookup-per-byte walk at 269.5 GB/s of input")
     if walked is not None:
         roofline["bytes_walked_per_launch"] = walked
         roofline["walked_frac_of_input"] = round(walked / max(1, wl.in_bytes), 4)
-        roofline["scanned_GBps"] = round(wl.in_bytes / (kernel_ms * 1e-3) / 1e9, 1)
+        roofline["scanned_GBps"] = round(wl.in_bytes * batches_per_launch / (kernel_ms * 1e-3) / 1e9, 1)
         roofline["algorithmic_note"] = ("achieved counts the bytes the reference's loop consumes "
                                         "(k_walked); scanned_GBps counts whole lines")
     roofline.update(calib)
@@ -713,9 +809,13 @@ def main():
             "hot_rows": wl.tuned or ("static choice" if info["table_kind"] == 6 else None),
             "working_set_bytes": len(wl.bufs) * wl.in_bytes,
             "streams": args.streams,
+            "steps_per_call": per_call,
             "value_is": ("steps issued round-robin on %d HIP streams: up to %d independent batches in "
                          "flight" % (args.streams, args.streams)) if args.streams > 1 else
-                        "steps back to back on one stream",
+                        ("one stream; the steps handed to redgpu_match_batches_dev %d at a time (one "
+                         "launch per call: table staged once, tiles handed out across the batches)"
+                         % per_call) if per_call > 1 else
+                        "steps back to back on one stream, one redgpu_match_batch_dev call each",
             "sharding": "contiguous shard per GPU, no data-path collective" +
                         ("; EVERY step's Outcomes gathered to rank 0 over %s as compact records "
                          "(pipelined, 2 in flight)" % ("RCCL" if backend == "nccl" else "gloo")

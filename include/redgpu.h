@@ -268,6 +268,35 @@ int redgpu_search_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, con
                             const uint64_t *offsets, uint64_t stride, uint64_t n,
                             int32_t *result, uint64_t *start, uint64_t *end, void *stream);
 
+/* ---- several device-resident batches per call ----------------------------------------------
+ * The reference's callers hold many inputs and loop over them (tools/bench.cpp:60-71: every
+ * line of the file, `iters` times; tools/thr_red.cpp:36-47).  A caller that holds K buffers of
+ * lines hands all K over at once:
+ *   redgpu_check_batches_dev <-> for each batch: check<style,doLeader> per line, Matcher.h:363-410
+ *   redgpu_match_batches_dev <-> for each batch: match<style,doLeader> per line, Matcher.h:413-495
+ * The results are exactly those of n_batches calls of the single-batch entry point in the order
+ * given, on `stream` (a batch may read what an earlier one wrote only through the single-batch
+ * calls: the batches of ONE call must not alias each other's outputs).  What the call buys: runs
+ * of consecutive batches that the streaming kernel takes - fixed stride, the same for all, a
+ * multiple of 64 bytes; styLast / styFull; the same outputs asked for (start NULL in all or in
+ * none) - go out as ONE launch per 32 batches in which the DFA table is staged once per CU and
+ * tiles of lines are handed out across batch boundaries, so the head and tail a 64 MiB launch
+ * pays (a third of it) are paid once per call.  Anything else in the list runs as its own launch,
+ * as redgpu_*_batch_dev would run it.  start / end of redgpu_batch are ignored by check. */
+typedef struct redgpu_batch {
+  const uint8_t  *data;
+  const uint64_t *offsets; /* n + 1 entries, or NULL: fixed stride */
+  uint64_t stride;
+  uint64_t n;
+  int32_t  *result;
+  uint64_t *start;         /* may be NULL */
+  uint64_t *end;           /* may be NULL */
+} redgpu_batch;
+int redgpu_check_batches_dev(const redgpu_dfa *dfa, int style, int do_leader,
+                             const redgpu_batch *batches, uint32_t n_batches, void *stream);
+int redgpu_match_batches_dev(const redgpu_dfa *dfa, int style, int do_leader,
+                             const redgpu_batch *batches, uint32_t n_batches, void *stream);
+
 int redgpu_collect_batch_dev(const redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offsets,
                              uint64_t stride, uint64_t n, uint64_t cap, uint64_t *counts,
                              int32_t *result, uint64_t *start, uint64_t *end, void *stream);

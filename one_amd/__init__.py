@@ -8,7 +8,7 @@ extension; the first call does, and fails loudly if it is not built.
 """
 from .matcher import (Executable, Group, Style, RedExcept, RedExceptApi, RedExceptExec,  # noqa: F401
                       RedExceptLimit, RedExceptHip, check, check_batch, check_header, match,
-                      match_batch, scan, scan_batch, search, search_batch, collect,
+                      match_batch, match_batches, check_batches, batch_descs, scan, scan_batch, search, search_batch, collect,
                       collect_batch, match_all, match_all_batch, advance_batch,
                       StatefulMatcher, STATE_INITIAL, split_lines, replace, replace_batch, last_kernel, styInstant, styFirst,
                       styTangent, styLast, styFull)
@@ -16,4 +16,5 @@ from .matcher import (Executable, Group, Style, RedExcept, RedExceptApi, RedExce
 __all__ = ["Executable", "Group", "Style", "check", "match", "scan", "check_batch", "match_batch",
            "scan_batch", "search", "search_batch", "collect", "collect_batch", "check_header",
            "match_all", "match_all_batch", "advance_batch", "StatefulMatcher", "STATE_INITIAL",
-           "split_lines", "replace", "replace_batch", "last_kernel"]
+           "split_lines", "replace", "replace_batch", "last_kernel", "match_batches",
+           "check_batches", "batch_descs"]

@@ -35,6 +35,12 @@ class Info(C.Structure):
                 ("suffix_closed", C.c_uint32)]
 
 
+class BatchDesc(C.Structure):  # redgpu_batch
+    _fields_ = [("data", C.c_void_p), ("offsets", C.c_void_p), ("stride", C.c_uint64),
+                ("n", C.c_uint64), ("result", C.c_void_p), ("start", C.c_void_p),
+                ("end", C.c_void_p)]
+
+
 def build(force: bool = False) -> str:
     """Compile libredgpu.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     if force:
@@ -107,6 +113,10 @@ def lib() -> C.CDLL:
             f = getattr(l, name)
             f.restype = C.c_int
             f.argtypes = [vp, i32, i32, vp, vp, u64, u64, vp, vp, vp, vp]
+        for name in ("redgpu_check_batches_dev", "redgpu_match_batches_dev"):
+            f = getattr(l, name)
+            f.restype = C.c_int
+            f.argtypes = [vp, i32, i32, C.POINTER(BatchDesc), C.c_uint32, vp]
         l.redgpu_collect_batch.restype = C.c_int
         l.redgpu_collect_batch.argtypes = [vp, vp, vp, u64, u64, u64, vp, vp, vp, vp]
         l.redgpu_collect_batch_dev.restype = C.c_int

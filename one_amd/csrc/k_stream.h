@@ -575,11 +575,15 @@ k_stream(DevDfa d, Batch io) {
           rr = s[c] >= firstAccept ? rr : 0;
           en = lineLen;
         }
-        *(report ? io.result + ln : reinterpret_cast<int32_t *>(d.sink)) = rr;
-        *(report && io.end ? io.end + ln : reinterpret_cast<uint64_t *>(d.sink)) = rr ? uint64_t(en) : 0;
+        // non-temporal: the Outcomes are written once and not read by this launch (round 3:
+        // configs[1]'s single launch 25.4 -> 23.7 us)
+        __builtin_nontemporal_store(rr, report ? io.result + ln : reinterpret_cast<int32_t *>(d.sink));
+        __builtin_nontemporal_store(rr ? uint64_t(en) : uint64_t(0),
+                                    report && io.end ? io.end + ln : reinterpret_cast<uint64_t *>(d.sink));
         if (kStart)
-          *(report && io.start ? io.start + ln : reinterpret_cast<uint64_t *>(d.sink)) =
-              rr ? uint64_t(startv[c]) : 0;
+          __builtin_nontemporal_store(rr ? uint64_t(startv[c]) : uint64_t(0),
+                                      report && io.start ? io.start + ln
+                                                         : reinterpret_cast<uint64_t *>(d.sink));
       }
       if (++r == R) { r = 0; tile += G; }
       return;

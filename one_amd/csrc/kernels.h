@@ -81,6 +81,17 @@ struct LaunchCfg {
 hipError_t launchBatch(const DevDfa &dfa, const Batch &b, int verb, int style, int doLeader,
                        const LaunchCfg &cfg, hipStream_t stream, const char **kernelName);
 
+// The same for nb batches in the order given, as nb calls of launchBatch on `stream` would run
+// them - except that runs of batches the streaming kernel takes (fixed stride, whole 64-byte
+// blocks, styles Last / Full of check / match) with one stride go out as ONE launch each
+// (k_stream_multi.h: table staged once, tiles handed out across batch boundaries).
+hipError_t launchBatches(const DevDfa &dfa, const Batch *bs, uint32_t nb, int verb, int style,
+                         int doLeader, const LaunchCfg &cfg, hipStream_t stream,
+                         const char **kernelName);
+hipError_t launchStreamBatches(const DevDfa &dfa, const Batch *bs, uint32_t nb, int verb, int style,
+                               int doLeader, const LaunchCfg &cfg, hipStream_t stream,
+                               const char **kernelName, uint32_t *taken);
+
 // Red::collect per line (lib/Red.cpp:103-116): up to `cap` records per line at
 // [line*cap, line*cap+cap) of result/start/end, counts[line] = number found.
 hipError_t launchCollect(const DevDfa &dfa, const Batch &b, uint64_t cap, uint64_t *counts,

@@ -1656,6 +1656,7 @@ k_leader_filter(DevDfa d, Batch b) {
 }
 
 #include "k_stream.h"
+#include "k_stream_multi.h"
 #include "k_ragged.h"
 
 // Red::collect (lib/Red.cpp:103-116): all non-overlapping matches of a line, in order, by
@@ -3036,6 +3037,9 @@ hipError_t launchAdvanceStream(const DevDfa &d, const Batch &b, uint32_t *state,
 #if REDGPU_TU_STREAM
 // The fixed-stride family of launchBatch: speculative chunks, k_stream (fused / hot / class
 // table), k_fixed.  *handled = false: not this family's batch.
+hipError_t launchStreamBatches(const DevDfa &d, const Batch *bs, uint32_t nb, int verb, int style,
+                               int doLeader, const LaunchCfg &cfg, hipStream_t stream,
+                               const char **kernelName, uint32_t *taken);
 hipError_t launchFixedFamily(const DevDfa &d, const Batch &b, int verb, int style, int doLeader,
                              const LaunchCfg &cfg, hipStream_t stream, const char **kernelName,
                              bool *handled) {
@@ -3094,6 +3098,12 @@ hipError_t launchFixedFamily(const DevDfa &d, const Batch &b, int verb, int styl
     hipError_t e;
     Batch sb = b;
     if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
+    static const int labSingle = multiLabInt("REDGPU_MULTI_SINGLE", 0, 1, 0);
+    if (labSingle) {  // lab: a single batch through the multi-batch kernel
+      uint32_t taken = 0;
+      e = launchStreamBatches(d, &b, 1, verb, style, doLeader, cfg, stream, kernelName, &taken);
+      if (e != hipSuccess || taken) return e;
+    }
     if (stream4Eligible(d, sb, cfg)) {
       const int mode = style == kStyLast ? (sb.start ? kSmLastStartEnd : kSmLastEnd)
                                          : (sb.start ? kSmFullStart : kSmFull);
@@ -3176,6 +3186,69 @@ hipError_t launchFixedFamily(const DevDfa &d, const Batch &b, int verb, int styl
   }
 
   *handled = false;
+  return hipSuccess;
+}
+
+// Several batches, one launch (k_stream_multi.h).  *taken = how many of bs[0..nb) the launch
+// covers: the longest run of leading batches that launchFixedFamily would each give to
+// k_stream's plain form, with one stride and the same outputs asked for; 0 = bs[0] is not
+// such a batch, or the run is a single batch (the caller then runs it on its own).
+hipError_t launchStreamBatches(const DevDfa &d, const Batch *bs, uint32_t nb, int verb, int style,
+                               int doLeader, const LaunchCfg &cfg, hipStream_t stream,
+                               const char **kernelName, uint32_t *taken) {
+  *taken = 0;
+  const bool lead = doLeader && d.leaderLen > 0;
+  const bool dying = d.earlyDeath && !cfg.forceStream;
+  if (cfg.forceGeneric || cfg.forceEarly || cfg.forceChunking || dying || !fastPathEligible(d) ||
+      !(verb == kCheck || verb == kMatch) || !(style == kStyLast || style == kStyFull) ||
+      (lead && verb == kCheck) || d.tableBytes > kStreamTabBytes || d.nStates > 256)
+    return hipSuccess;
+  auto plain = [&](const Batch &b) {
+    // (few long lines over a forgetful DFA are launchFixedFamily's speculative chunks)
+    const bool chunky = fewLines(b, cfg) && d.forgetful && !cfg.noChunking && b.stride >= 4096;
+    return !b.offsets && b.stride >= 64 && b.stride % 64 == 0 && b.stride < (1ull << 31) &&
+           (reinterpret_cast<uintptr_t>(b.data) % 16) == 0 && b.n > 0 && !chunky &&
+           b.n < (1ull << 40) && !stream4Eligible(d, b, cfg);
+  };
+  const bool wantStart = verb == kMatch && bs[0].start;
+  MultiIo m;
+  m.nb = 0;
+  m.lineLen = uint32_t(bs[0].stride);
+  m.tileStart[0] = 0;
+  const uint64_t lpt = uint64_t(kStreamThreads) * kStreamChains;
+  for (uint32_t k = 0; k < nb && m.nb < uint32_t(kMultiMax); ++k) {
+    const Batch &b = bs[k];
+    if (!plain(b) || b.stride != bs[0].stride || (verb == kMatch && bool(b.start) != wantStart))
+      break;
+    const uint64_t tiles = (b.n + lpt - 1) / lpt;
+    if (uint64_t(m.tileStart[m.nb]) + tiles >= (1ull << 31)) break;
+    m.b[m.nb] = MultiPtrs{b.data, b.result, verb == kMatch ? b.start : nullptr,
+                          verb == kMatch ? b.end : nullptr, b.n};
+    m.tileStart[m.nb + 1] = m.tileStart[m.nb] + uint32_t(tiles);
+    ++m.nb;
+  }
+  // (fewer tiles than CUs in all: the single-batch launches spread such lines better)
+  static const int labSingle = multiLabInt("REDGPU_MULTI_SINGLE", 0, 1, 0);  // lab: nb = 1 too
+  if (m.nb < (labSingle ? 1u : 2u) || m.tileStart[m.nb] < uint32_t(cfg.numCUs)) return hipSuccess;
+  for (uint32_t k = m.nb; k < uint32_t(kMultiMax) + 1; ++k) m.tileStart[k + 1] = m.tileStart[m.nb];
+  hipError_t e;
+  if (style == kStyLast) {
+    if (wantStart) { *kernelName = "k_stream_multi<last,start,end>"; e = launchStreamMultiT<kSmLastStartEnd>(d, m, cfg, stream); }
+    else { *kernelName = "k_stream_multi<last,end>"; e = launchStreamMultiT<kSmLastEnd>(d, m, cfg, stream); }
+  } else {
+    if (wantStart) { *kernelName = "k_stream_multi<full,start>"; e = launchStreamMultiT<kSmFullStart>(d, m, cfg, stream); }
+    else { *kernelName = "k_stream_multi<full>"; e = launchStreamMultiT<kSmFull>(d, m, cfg, stream); }
+  }
+  if (e != hipSuccess) return e;
+  if (lead) {
+    // match<..., true> only peeks the leader (Matcher.h:424-435): lines that fail it report {0,0,0}
+    for (uint32_t k = 0; k < m.nb; ++k) {
+      hipLaunchKernelGGL(k_leader_filter, dim3(uint32_t(cfg.numCUs) * 8), dim3(256), 0, stream, d,
+                         bs[k]);
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+  }
+  *taken = m.nb;
   return hipSuccess;
 }
 #endif  // REDGPU_TU_STREAM
@@ -3429,13 +3502,9 @@ hipError_t launchAdvance(const DevDfa &d, const Batch &b, uint32_t *state, const
 #undef AD_CALL
 }
 
-hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int doLeader,
-                       const LaunchCfg &cfg, hipStream_t stream, const char **kernelName) {
-  if (b.n == 0) {
-    *kernelName = "none";
-    return hipSuccess;
-  }
-  const bool lead = doLeader && d.leaderLen > 0;
+// The identities launchBatch applies before it picks a kernel.
+static void normalizeVerbStyle(const DevDfa &d, const LaunchCfg &cfg, bool lead, int &verb,
+                               int &style) {
   // L = SIGMA* L (DfaImage::suffixClosed - patterns added with a loose start) and no leader: the
   // sliding loops of scan and search (Matcher.h:511-553, :575-621) ARE their first attempt.  It
   // cannot meet a pure dead end (from any reachable state something is still accepted), so it
@@ -3454,6 +3523,38 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
   if (verb == kCheck && !lead && d.uniformResult && !d.earlyDeath && !cfg.forceGeneric &&
       (style == kStyInstant || style == kStyFirst || style == kStyTangent))
     style = kStyLast;
+}
+
+hipError_t launchBatches(const DevDfa &d, const Batch *bs, uint32_t nb, int verb, int style,
+                         int doLeader, const LaunchCfg &cfg, hipStream_t stream,
+                         const char **kernelName) {
+  *kernelName = "none";
+  int nverb = verb, nstyle = style;
+  normalizeVerbStyle(d, cfg, doLeader && d.leaderLen > 0, nverb, nstyle);
+  for (uint32_t k = 0; k < nb;) {
+    if (bs[k].n == 0) { ++k; continue; }
+    uint32_t taken = 0;
+    hipError_t e = launchStreamBatches(d, bs + k, nb - k, nverb, nstyle, doLeader, cfg, stream,
+                                       kernelName, &taken);
+    if (e != hipSuccess) return e;
+    if (!taken) {
+      e = launchBatch(d, bs[k], verb, style, doLeader, cfg, stream, kernelName);
+      if (e != hipSuccess) return e;
+      taken = 1;
+    }
+    k += taken;
+  }
+  return hipSuccess;
+}
+
+hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int doLeader,
+                       const LaunchCfg &cfg, hipStream_t stream, const char **kernelName) {
+  if (b.n == 0) {
+    *kernelName = "none";
+    return hipSuccess;
+  }
+  const bool lead = doLeader && d.leaderLen > 0;
+  normalizeVerbStyle(d, cfg, lead, verb, style);
   // DFAs the visit model sees dying within 16 bytes (anchored patterns on arbitrary text) stay
   // with k_generic: the whole-line kernels below read and walk every byte, k_generic stops
   // where the reference's loop stops - measured on ERR 1.3x (64-byte lines) to 38x (4 KiB

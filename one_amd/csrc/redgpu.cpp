@@ -30,6 +30,17 @@ int checkStyle(int style) {
   return REDGPU_OK;
 }
 
+LaunchCfg cfgOf(const redgpu_dfa *dfa, uint32_t extraFlags = 0) {
+  return LaunchCfg{dfa->numCUs, ((dfa->flags | extraFlags) & REDGPU_F_FORCE_GENERIC) ? 1 : 0,
+                   (dfa->flags & REDGPU_F_NO_BUCKETING) ? 1 : 0,
+                   (dfa->flags & REDGPU_F_FORCE_STREAM) ? 1 : 0,
+                   (dfa->flags & REDGPU_F_NO_CHUNKING) ? 1 : 0,
+                   (dfa->flags & REDGPU_F_FORCE_CHUNKING) ? 1 : 0,
+                   (dfa->flags & REDGPU_F_FORCE_EARLY) ? 1 : 0,
+                   (dfa->flags & REDGPU_F_STREAM_CHAINS_2) ? 2
+                   : (dfa->flags & REDGPU_F_STREAM_CHAINS_4) ? 4 : 0};
+}
+
 int runDev(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint8_t *data,
            const uint64_t *offsets, uint64_t stride, uint64_t n, int32_t *result,
            uint64_t *start, uint64_t *end, hipStream_t stream, uint32_t extraFlags = 0) {
@@ -45,16 +56,46 @@ int runDev(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint8
   DeviceScope scope(dfa->im->device);
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   Batch b{data, offsets, stride, n, result, start, end};
-  LaunchCfg cfg{dfa->numCUs, ((dfa->flags | extraFlags) & REDGPU_F_FORCE_GENERIC) ? 1 : 0,
-                (dfa->flags & REDGPU_F_NO_BUCKETING) ? 1 : 0,
-                (dfa->flags & REDGPU_F_FORCE_STREAM) ? 1 : 0,
-                (dfa->flags & REDGPU_F_NO_CHUNKING) ? 1 : 0,
-                (dfa->flags & REDGPU_F_FORCE_CHUNKING) ? 1 : 0,
-                (dfa->flags & REDGPU_F_FORCE_EARLY) ? 1 : 0,
-                (dfa->flags & REDGPU_F_STREAM_CHAINS_2) ? 2
-                : (dfa->flags & REDGPU_F_STREAM_CHAINS_4) ? 4 : 0};
+  const LaunchCfg cfg = cfgOf(dfa, extraFlags);
   const char *name = "";
   hipError_t e = launchBatch(dfa->im->dev, b, verb, style, doLeader ? 1 : 0, cfg, stream, &name);
+  tlsKernel = name;
+  if (e != hipSuccess) return failHip(e, "kernel launch");
+  return REDGPU_OK;
+}
+
+// K batches, in order, on one stream (redgpu_*_batches_dev): each validated as runDev validates
+// its one batch, then handed to launchBatches, which folds runs of streaming-kernel batches
+// into single launches.
+int runDevMany(const redgpu_dfa *dfa, int verb, int style, int doLeader, const redgpu_batch *bs,
+               uint32_t nb, hipStream_t stream) {
+  if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
+  if (dfa->im->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (int rc = checkStyle(style)) return rc;
+  if (nb == 0) return REDGPU_OK;
+  if (!bs) return fail(REDGPU_EAPI, "null batch descriptors");
+  std::vector<Batch> v;
+  v.reserve(nb);
+  for (uint32_t k = 0; k < nb; ++k) {
+    const redgpu_batch &b = bs[k];
+    if (b.n == 0) continue;
+    if (!b.result) return fail(REDGPU_EAPI, "null result buffer");
+    if (!b.data && (b.offsets || b.stride)) return fail(REDGPU_EAPI, "null data buffer");
+    if (!b.offsets && b.stride >= (1ull << 40)) return fail(REDGPU_ELIMIT, "stride too large");
+    if (b.offsets && b.stride > 16)
+      return fail(REDGPU_EAPI, "with offsets, stride is the number of trailing bytes to drop "
+                               "per line (0..16)");
+    const bool pos = verb == kMatch || verb == kSearch;
+    v.push_back(Batch{b.data, b.offsets, b.stride, b.n, b.result, pos ? b.start : nullptr,
+                      pos ? b.end : nullptr});
+  }
+  if (v.empty()) return REDGPU_OK;
+  DeviceScope scope(dfa->im->device);
+  if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  const LaunchCfg cfg = cfgOf(dfa);
+  const char *name = "";
+  hipError_t e = launchBatches(dfa->im->dev, v.data(), uint32_t(v.size()), verb, style,
+                               doLeader ? 1 : 0, cfg, stream, &name);
   tlsKernel = name;
   if (e != hipSuccess) return failHip(e, "kernel launch");
   return REDGPU_OK;
@@ -970,6 +1011,18 @@ int redgpu_match_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, cons
                            int32_t *result, uint64_t *start, uint64_t *end, void *stream) {
   return runDev(dfa, kMatch, style, do_leader, data, offsets, stride, n, result, start, end,
                 static_cast<hipStream_t>(stream));
+}
+
+int redgpu_check_batches_dev(const redgpu_dfa *dfa, int style, int do_leader,
+                             const redgpu_batch *batches, uint32_t n_batches, void *stream) {
+  return runDevMany(dfa, kCheck, style, do_leader, batches, n_batches,
+                    static_cast<hipStream_t>(stream));
+}
+
+int redgpu_match_batches_dev(const redgpu_dfa *dfa, int style, int do_leader,
+                             const redgpu_batch *batches, uint32_t n_batches, void *stream) {
+  return runDevMany(dfa, kMatch, style, do_leader, batches, n_batches,
+                    static_cast<hipStream_t>(stream));
 }
 
 int redgpu_scan_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,

@@ -352,6 +352,60 @@ def match_batch(exe, data, style, do_leader=True, *, offsets=None, stride=0, n=N
                 out)
 
 
+def batch_descs(batches, *, stride=0, want_start=True, want_end=True, outs=None, verb="match"):
+    """The redgpu_batch array of a *_batches_dev call over CUDA tensors.  batches[k] = data, or
+    (data, offsets) for ragged lines; outs[k] = (result, start, end) tensors (allocated when None).
+    Returns (descriptor array, outs) - keep both alive until the stream has passed the call."""
+    import torch
+    pos = verb == "match"
+    descs = (_lib.BatchDesc * len(batches))()
+    made = []
+    for k, sh in enumerate(batches):
+        d, o = sh if isinstance(sh, tuple) else (sh, None)
+        if not _is_torch(d) or not d.is_cuda or d.dtype != torch.uint8 or not d.is_contiguous():
+            raise RedExceptApi("device input must be a contiguous uint8 CUDA tensor")
+        n = (o.numel() - 1) if o is not None else (d.numel() // stride if stride else 0)
+        if outs is None or outs[k] is None:
+            res = torch.empty(n, dtype=torch.int32, device=d.device)
+            st = torch.empty(n, dtype=torch.int64, device=d.device) if pos and want_start else None
+            en = torch.empty(n, dtype=torch.int64, device=d.device) if pos and want_end else None
+        else:
+            res, st, en = outs[k]
+        made.append((res, st, en))
+        descs[k] = _lib.BatchDesc(d.data_ptr(), o.data_ptr() if o is not None else None,
+                                  int(stride or 0), n, res.data_ptr(),
+                                  st.data_ptr() if st is not None else None,
+                                  en.data_ptr() if en is not None else None)
+    return descs, made
+
+
+def match_batches(exe, batches, style, do_leader=True, *, stride=0, want_start=True,
+                  want_end=True, outs=None):
+    """match<style,doLeader> over every line of SEVERAL device-resident batches in one call
+    (redgpu_match_batches_dev: the caller's loop over its inputs, tools/bench.cpp:60-71) ->
+    [(result, start, end)] per batch, complete on torch's current stream."""
+    import torch
+    descs, made = batch_descs(batches, stride=stride, want_start=want_start, want_end=want_end,
+                              outs=outs)
+    dev = (batches[0][0] if isinstance(batches[0], tuple) else batches[0]).device
+    _check(_lib.lib().redgpu_match_batches_dev(exe._h, int(style), 1 if do_leader else 0, descs,
+                                               len(batches),
+                                               torch.cuda.current_stream(dev).cuda_stream))
+    return made
+
+
+def check_batches(exe, batches, style, do_leader=True, *, stride=0, outs=None):
+    """check<style,doLeader> over several device-resident batches in one call -> [result]."""
+    import torch
+    descs, made = batch_descs(batches, stride=stride, outs=None if outs is None else
+                              [(o, None, None) for o in outs], verb="check")
+    dev = (batches[0][0] if isinstance(batches[0], tuple) else batches[0]).device
+    _check(_lib.lib().redgpu_check_batches_dev(exe._h, int(style), 1 if do_leader else 0, descs,
+                                               len(batches),
+                                               torch.cuda.current_stream(dev).cuda_stream))
+    return [m[0] for m in made]
+
+
 def search_batch(exe, data, style, do_leader=True, *, offsets=None, stride=0, n=None,
                  want_start=True, want_end=True, out=None):
     """search<style,doLeader> over every line (include/Matcher.h:557-640): the first match found

@@ -398,8 +398,25 @@ def main():
             raise RuntimeError(_lib.lib().redgpu_last_error().decode())
         last_call[:] = [((i + k) % len(wl.bufs), (i + k) % len(wl.outs)) for k in range(cnt)]
 
+    plans = {}
+
+    def plan_of(count):
+        """the multi-batch calls of `count` steps: (descriptor window, steps in it), built once"""
+        if count not in plans:
+            plans[count] = [(window(i, min(per_call, count - i)), min(per_call, count - i), i)
+                            for i in range(0, count, per_call)]
+        return plans[count]
+
     def run_steps(count):
         """`count` steps, the way this run issues them; returns the last step's outputs"""
+        if per_call > 1:
+            h, sty, lead = wl.exe._h, wl.style, wl.lead
+            for win, cnt, i in plan_of(count):
+                if fn_many(h, sty, lead, win, cnt, cur_stream) != 0:
+                    raise RuntimeError(_lib.lib().redgpu_last_error().decode())
+            if count:
+                last_call[:] = [((i + k) % len(wl.bufs), (i + k) % len(wl.outs)) for k in range(cnt)]
+            return wl.outs[(count - 1) % len(wl.outs)]
         if per_call <= 1:
             o = None
             for i in range(count):
@@ -441,10 +458,8 @@ def main():
         dist.barrier()
 
     if per_call > 1:  # the timed loop's descriptor windows, before any clock starts
-        for i in range(0, max(args.steps, args.warmup), per_call):
-            for count in (args.steps, args.warmup):
-                if i < count:
-                    window(i, min(per_call, count - i))
+        plan_of(args.steps)
+        plan_of(args.warmup)
     # (the two events exist - torch creates the HIP event at its first record() - before any clock
     # starts: creating them inside the timed region cost ~50 us of a 0.4 ms region)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -640,6 +655,43 @@ def main():
                                                 "launch (not the workload: shows the launch's head + tail)" %
                                                 (big_n, wl.L))
             del big, br, bs, be
+        # (c2b) the memory side of this shape alone: 64 B read + 20 B written per line, requested and
+        # stored the way the walk does, no table, no steps - the HBM roof of configs[1]'s shape
+        if args.config == 1 and wl.L == 64 and wl.want_start:
+            big_n = n * 16
+            big = torch.empty(big_n * wl.L, dtype=torch.uint8, device="cuda").random_(0, 256)
+            br = torch.empty(big_n, dtype=torch.int32, device="cuda")
+            bs = torch.empty(big_n, dtype=torch.int64, device="cuda")
+            be = torch.empty(big_n, dtype=torch.int64, device="cuda")
+            margs = (wl.exe._h, big.data_ptr(), big_n, 64, br.data_ptr(), bs.data_ptr(), be.data_ptr(),
+                     sink.data_ptr(), cur_stream)
+            for _ in range(2):
+                l.redgpu_diag_lines_dev(*margs)
+            c0.record()
+            for _ in range(5):
+                l.redgpu_diag_lines_dev(*margs)
+            c1.record()
+            torch.cuda.synchronize()
+            calib["lines64_memory_roof_GBps"] = round(5 * big_n * wl.L / (c0.elapsed_time(c1) * 1e-3) / 1e9, 1)
+            calib["lines64_memory_roof_how"] = ("k_diag_lines: %d lines x 64 B read as the walk requests them + "
+                                                "an int32 and two uint64 stored per line, nothing else; GB/s of "
+                                                "INPUT (x 84/64 = HBM traffic)" % big_n)
+            del big, br, bs, be
+        # (c2c) long lines: what HBM gives the request pattern itself - one cache line per lane and
+        # request, the lanes of a wave a whole line length apart - reads only
+        if args.config in (2, 4) and not wl.ragged and wl.L % 128 == 0:
+            margs = (wl.exe._h, wl.bufs[0].data_ptr(), n, wl.L, None, None, None, sink.data_ptr(), cur_stream)
+            for _ in range(2):
+                l.redgpu_diag_lines_dev(*margs)
+            c0.record()
+            for _ in range(3):
+                l.redgpu_diag_lines_dev(*margs)
+            c1.record()
+            torch.cuda.synchronize()
+            calib["long_line_pattern_roof_GBps"] = round(3 * (n // 1024 * 1024) * wl.L / (c0.elapsed_time(c1) * 1e-3) / 1e9, 1)
+            calib["long_line_pattern_roof_how"] = ("k_diag_long: the batch's own bytes requested as the walk "
+                                                   "requests them (128 B per lane and request, 2 lines per lane, "
+                                                   "lanes %d B apart), no table, no steps, no stores" % wl.L)
         # (c3) the north star's literal outputs - result code and end offset, no start: the same
         # batch through the same entry point with start = NULL (12 B written per line, not 20)
         if wl.want_start and not wl.ragged and args.config in (1, 2):

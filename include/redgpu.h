@@ -80,6 +80,14 @@ typedef struct redgpu_opts {
                                          (default: by batch size; tests, tuning) */
 #define REDGPU_F_FORCE_EARLY 512u /* match: the probe-and-drain kernel of the early-death DFAs for any
                                     LDS-resident table and any batch size (tests, tuning) */
+#define REDGPU_F_FORCE_LEAN 1024u /* fixed-stride lines of 512 bytes and more: the deferred-bookkeeping
+                                     step (k_stream_lean.h: 2.75 VALU per byte instead of 6, the two
+                                     pieces that hold a line's last accept and last start re-walked at
+                                     its end) instead of the exact one.  Built because the exact step
+                                     looked issue-bound; measured it is not - 4 KiB lines +2 % (URI-D)
+                                     / -3 % (SYN-256), 512-byte lines -8 % - so it is opt-in */
+#define REDGPU_F_LEAN_CHAINS_4 2048u /* ... with four lines per lane (two chain groups, counted
+                                     waits) instead of two */
 #define REDGPU_F_FORCE_HOT     4u /* a table too big for LDS always gets hot rows in LDS, even
                                      when the visit model finds no locality (tests, tuning) */
 
@@ -252,9 +260,12 @@ int redgpu_replace_batch(const redgpu_dfa *dfa, int style, int do_leader, const 
 /* ---- the same verbs over DEVICE-resident buffers, asynchronous on `stream` ---------------
  * data/offsets/result/start/end are device pointers on the handle's device; `stream` is a
  * hipStream_t (NULL = the default stream).  Nothing is copied or synchronised; the only
- * allocation is the ragged fast path's scratch (4 bytes per line for its length-bucketing
- * pass), kept per host thread and stream and re-used by later calls - it is (re)allocated, with
- * a device synchronisation, only when a call needs more than the cached buffer holds. */
+ * allocation is the scratch some launches need (the ragged kernels' tail pad and length buckets,
+ * the chunked walk's records, replace's partial sums): kept per HOST THREAD and (device, stream)
+ * and re-used by that thread's later calls on the stream - so any number of threads may issue
+ * _dev calls on one stream, the default one included - (re)allocated, with a device
+ * synchronisation, only when a call needs more than the cached buffer holds; freed when the
+ * thread exits or calls redgpu_thread_release(). */
 int redgpu_check_batch_dev(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
                            const uint64_t *offsets, uint64_t stride, uint64_t n,
                            int32_t *result, void *stream);
@@ -349,15 +360,28 @@ int redgpu_diag_read_dev(const redgpu_dfa *dfa, const void *data, uint64_t bytes
  *    bytes an early-exit walk actually reads, as opposed to the bytes of the lines. */
 int redgpu_diag_lds_dev(const redgpu_dfa *dfa, uint32_t rounds, uint32_t *sink, uint64_t *lookups,
                         void *stream);
+/*  - redgpu_diag_lines_dev: the memory side of the fixed-stride walk and nothing else.
+ *    line_bytes = 64: every lane requests its line the way the streaming kernel does and stores
+ *    one Outcome-shaped record per line (result int32, start / end uint64; the values are
+ *    meaningless) - 64 B read + 20 B written per line; what HBM sustains for that mix is the roof
+ *    of BASELINE configs[1]'s shape.  line_bytes a multiple of 128: the long-line request pattern
+ *    (a lane asks for one whole cache line of each of its two lines at a time, so a wave touches
+ *    64 cache lines a line length apart), reads only (result / start / end may be NULL) - the
+ *    roof of configs[2]'s and configs[4]'s shapes.  n_lines is rounded down to a multiple of
+ *    1024. */
+int redgpu_diag_lines_dev(const redgpu_dfa *dfa, const uint8_t *data, uint64_t n_lines,
+                          uint64_t line_bytes, int32_t *result, uint64_t *start, uint64_t *end,
+                          uint32_t *sink, void *stream);
 int redgpu_diag_walked_dev(const redgpu_dfa *dfa, int do_leader, const uint8_t *data,
                            const uint64_t *offsets, uint64_t stride, uint64_t n, uint64_t *walked,
                            void *stream);
 
 /* The host-buffer entry points stage through device buffers and two private streams that each
  * HOST THREAD keeps per device (no allocation, stream creation or device-wide synchronisation per
- * call).  They are released when the thread exits; a long-lived thread that is done with the
- * library may release them early.  redgpu_scratch_entries: device scratch buffers the launches
- * currently cache process-wide (bounded; diagnostics / tests). */
+ * call).  They - and the thread's launch scratch - are released when the thread exits; a
+ * long-lived thread that is done with the library may release them early.
+ * redgpu_scratch_entries: launch scratch buffers currently cached by all threads together
+ * (bounded per thread; diagnostics / tests). */
 void redgpu_thread_release(void);
 uint64_t redgpu_scratch_entries(void);
 

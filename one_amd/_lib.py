@@ -15,7 +15,7 @@ GATHER_PEER, GATHER_RCCL = 0, 1
 DEVICE_CURRENT, DEVICE_NONE = -1, -2
 F_FORCE_GENERIC, F_FORCE_GLOBAL, F_FORCE_HOT, F_NO_BUCKETING, F_FORCE_STREAM = 1, 2, 4, 8, 16
 F_NO_CHUNKING, F_FORCE_CHUNKING = 32, 64
-F_STREAM_CHAINS_2, F_STREAM_CHAINS_4, F_FORCE_EARLY = 128, 256, 512
+F_STREAM_CHAINS_2, F_STREAM_CHAINS_4, F_FORCE_EARLY, F_FORCE_LEAN, F_LEAN_CHAINS_4 = 128, 256, 512, 1024, 2048
 
 
 class Opts(C.Structure):
@@ -148,6 +148,8 @@ def lib() -> C.CDLL:
         l.redgpu_diag_read_dev.argtypes = [vp, vp, u64, vp, vp]
         l.redgpu_diag_lds_dev.restype = C.c_int
         l.redgpu_diag_lds_dev.argtypes = [vp, C.c_uint32, vp, C.POINTER(u64), vp]
+        l.redgpu_diag_lines_dev.restype = C.c_int
+        l.redgpu_diag_lines_dev.argtypes = [vp, vp, u64, u64, vp, vp, vp, vp, vp]
         l.redgpu_diag_walked_dev.restype = C.c_int
         l.redgpu_diag_walked_dev.argtypes = [vp, i32, vp, vp, u64, u64, vp, vp]
         l.redgpu_thread_release.restype = None

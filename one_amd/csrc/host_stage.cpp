@@ -1,9 +1,9 @@
-// host_stage.cpp - per-thread staging for the host-buffer entry points, and the process-wide
+// host_stage.cpp - per-thread staging for the host-buffer entry points, and the per-thread
 // scratch pool of the ragged / chunked launches (see host_stage.h, kernels.h).
 #include "host_stage.h"
 
+#include <atomic>
 #include <memory>
-#include <mutex>
 #include <vector>
 
 #include "kernels.h"
@@ -11,12 +11,16 @@
 namespace redgpu {
 
 // ---- scratch pool ---------------------------------------------------------------------------
-// Device scratch of the ragged launches (tail pad, permutation, histograms, chunk records),
-// keyed by (device, stream): work queued on one stream runs in order, so the next launch on that
-// stream may reuse the buffer the previous one used; another stream gets its own.  Round 1 kept
-// these in thread_local slots that were never freed at thread exit; the pool is
-// process-wide, bounded (least recently used entry freed beyond kMaxEntries) and entries of a
-// stream this library created are dropped with that stream.
+// Device scratch of the ragged / chunked / replace launches (tail pad, permutation, histograms,
+// chunk records).  Those are multi-kernel sequences that carry state in the buffer from one
+// launch to the next, so a buffer must belong to ONE caller: the pool is per HOST THREAD, keyed
+// by (device, stream) - work a thread queues on one stream runs in order, so its next call on
+// that stream may reuse the buffer; another stream, or another thread on the same stream, gets
+// its own (round 2 shared one buffer per (device, stream) process-wide: two threads on the
+// default stream overwrote each other's tail pads, and growing the buffer freed a pointer the
+// other thread had not launched with yet).  Bounded per thread (least recently used entry
+// freed beyond kMaxPerThread), freed at thread exit and by redgpu_thread_release(); entries of
+// a stream this library created are dropped with the stream.
 namespace {
 
 struct ScratchEntry {
@@ -26,10 +30,31 @@ struct ScratchEntry {
   size_t bytes;
   uint64_t stamp;
 };
-constexpr size_t kMaxEntries = 64;
-std::mutex gScratchMutex;
-std::vector<ScratchEntry> gScratch;
-uint64_t gStamp = 0;
+constexpr size_t kMaxPerThread = 16;
+std::atomic<size_t> gScratchCount{0};  // entries alive in all threads (redgpu_scratch_entries)
+
+void freeEntry(ScratchEntry &en) {
+  if (!en.ptr) return;
+  int cur = -1;
+  const bool sw = hipGetDevice(&cur) == hipSuccess && cur != en.dev &&
+                  hipSetDevice(en.dev) == hipSuccess;
+  (void)hipFree(en.ptr);  // waits for the work that may still be using it
+  if (sw) (void)hipSetDevice(cur);
+  en.ptr = nullptr;
+  en.bytes = 0;
+}
+
+struct ThreadScratch {
+  std::vector<ScratchEntry> v;
+  uint64_t stamp = 0;
+  void clear() {
+    for (auto &en : v) freeEntry(en);
+    gScratchCount -= v.size();
+    v.clear();
+  }
+  ~ThreadScratch() { clear(); }
+};
+thread_local ThreadScratch tlsScratch;
 
 }  // namespace
 
@@ -37,67 +62,59 @@ hipError_t scratchFor(hipStream_t stream, size_t bytes, void **out) {
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  std::lock_guard<std::mutex> lock(gScratchMutex);
+  ThreadScratch &ts = tlsScratch;
   ScratchEntry *slot = nullptr;
-  for (auto &en : gScratch)
+  for (auto &en : ts.v)
     if (en.dev == dev && en.stream == stream) slot = &en;
   if (slot && slot->bytes >= bytes) {
-    slot->stamp = ++gStamp;
+    slot->stamp = ++ts.stamp;
     *out = slot->ptr;
     return hipSuccess;
   }
   if (!slot) {
-    if (gScratch.size() >= kMaxEntries) {
+    if (ts.v.size() >= kMaxPerThread) {
       size_t lru = 0;
-      for (size_t i = 1; i < gScratch.size(); ++i)
-        if (gScratch[i].stamp < gScratch[lru].stamp) lru = i;
-      if (gScratch[lru].dev == dev) {
-        (void)hipFree(gScratch[lru].ptr);  // waits for the work that may still be using it
-      } else {
-        int prev = dev;
-        (void)hipSetDevice(gScratch[lru].dev);
-        (void)hipFree(gScratch[lru].ptr);
-        (void)hipSetDevice(prev);
-      }
-      gScratch.erase(gScratch.begin() + long(lru));
+      for (size_t i = 1; i < ts.v.size(); ++i)
+        if (ts.v[i].stamp < ts.v[lru].stamp) lru = i;
+      freeEntry(ts.v[lru]);
+      ts.v.erase(ts.v.begin() + long(lru));
+      --gScratchCount;
     }
-    gScratch.push_back(ScratchEntry{dev, stream, nullptr, 0, 0});
-    slot = &gScratch.back();
+    ts.v.push_back(ScratchEntry{dev, stream, nullptr, 0, 0});
+    ++gScratchCount;
+    slot = &ts.v.back();
   }
-  if (slot->ptr) {
-    (void)hipFree(slot->ptr);
-    slot->ptr = nullptr;
-    slot->bytes = 0;
-  }
+  freeEntry(*slot);
   const size_t want = bytes + bytes / 2 + 4096;
   e = hipMalloc(&slot->ptr, want);
   if (e != hipSuccess) {
     slot->ptr = nullptr;
-    gScratch.erase(gScratch.begin() + (slot - gScratch.data()));
+    ts.v.erase(ts.v.begin() + (slot - ts.v.data()));
+    --gScratchCount;
     return e;
   }
   slot->bytes = want;
-  slot->stamp = ++gStamp;
+  slot->stamp = ++ts.stamp;
   *out = slot->ptr;
   return hipSuccess;
 }
 
 void scratchDrop(int device, hipStream_t stream) {
-  std::lock_guard<std::mutex> lock(gScratchMutex);
-  for (size_t i = 0; i < gScratch.size();) {
-    if (gScratch[i].dev == device && gScratch[i].stream == stream) {
-      (void)hipFree(gScratch[i].ptr);
-      gScratch.erase(gScratch.begin() + long(i));
+  ThreadScratch &ts = tlsScratch;
+  for (size_t i = 0; i < ts.v.size();) {
+    if (ts.v[i].dev == device && ts.v[i].stream == stream) {
+      freeEntry(ts.v[i]);
+      ts.v.erase(ts.v.begin() + long(i));
+      --gScratchCount;
     } else {
       ++i;
     }
   }
 }
 
-size_t scratchEntries() {
-  std::lock_guard<std::mutex> lock(gScratchMutex);
-  return gScratch.size();
-}
+void scratchReleaseThread() { tlsScratch.clear(); }
+
+size_t scratchEntries() { return gScratchCount.load(); }
 
 // ---- per-thread stages -------------------------------------------------------------------
 hipError_t HostStage::get(int slot, size_t bytes, void **out) {
@@ -186,7 +203,10 @@ hipError_t hostStage(int device, HostStage **out) {
   return hipSuccess;
 }
 
-void hostStageReleaseThread() { tlsStages.v.clear(); }
+void hostStageReleaseThread() {
+  tlsStages.v.clear();
+  scratchReleaseThread();
+}
 
 ScopedPin::ScopedPin(const void *ptr, size_t bytes, bool enable) {
   if (!enable || !ptr || !bytes) return;

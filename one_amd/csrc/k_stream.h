@@ -575,15 +575,23 @@ k_stream(DevDfa d, Batch io) {
           rr = s[c] >= firstAccept ? rr : 0;
           en = lineLen;
         }
-        // non-temporal: the Outcomes are written once and not read by this launch (round 3:
-        // configs[1]'s single launch 25.4 -> 23.7 us)
-        __builtin_nontemporal_store(rr, report ? io.result + ln : reinterpret_cast<int32_t *>(d.sink));
-        __builtin_nontemporal_store(rr ? uint64_t(en) : uint64_t(0),
-                                    report && io.end ? io.end + ln : reinterpret_cast<uint64_t *>(d.sink));
-        if (kStart)
-          __builtin_nontemporal_store(rr ? uint64_t(startv[c]) : uint64_t(0),
-                                      report && io.start ? io.start + ln
-                                                         : reinterpret_cast<uint64_t *>(d.sink));
+        int32_t *pr = report ? io.result + ln : reinterpret_cast<int32_t *>(d.sink);
+        uint64_t *pe = report && io.end ? io.end + ln : reinterpret_cast<uint64_t *>(d.sink);
+        uint64_t *ps = report && io.start ? io.start + ln : reinterpret_cast<uint64_t *>(d.sink);
+        if (R == 1) {
+          // one block per line, every store a line's Outcome - written once, not read by this
+          // launch: non-temporal (round 3: configs[1]'s single launch 25.4 -> 23.7 us).  Both arms
+          // issue the same number of stores, so the waits behind them stay exact.
+          __builtin_nontemporal_store(rr, pr);
+          __builtin_nontemporal_store(rr ? uint64_t(en) : uint64_t(0), pe);
+          if (kStart) __builtin_nontemporal_store(rr ? uint64_t(startv[c]) : uint64_t(0), ps);
+        } else {
+          // longer lines: most of these stores rewrite the sink, which must stay a cached line
+          // (non-temporal, every block's sink stores went out to HBM: 4 KiB lines 4.4 -> 3.1 TB/s)
+          *pr = rr;
+          *pe = rr ? uint64_t(en) : 0;
+          if (kStart) *ps = rr ? uint64_t(startv[c]) : 0;
+        }
       }
       if (++r == R) { r = 0; tile += G; }
       return;

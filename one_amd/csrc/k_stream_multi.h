@@ -44,13 +44,18 @@ __device__ __forceinline__ uint4 ntLoad16(const uint8_t *p) {
 // not read by this launch; with two workgroups per CU the 20-batch configs[1] launch took 319 us
 // against 345-349 us for either measure alone and for neither, r3 lab); bit 0: non-temporal
 // input loads too (lab only: slower, 465 against 421 us).  REDGPU_MULTI_NT picks another value.
-template <int MODE, int HALVES, int THREADS, int NT = 2>
+// LEAN: the deferred-bookkeeping step of k_stream_lean.h (long lines; the two remembered pieces of
+// a line are re-walked exactly when the line ends).
+// GR: groups of two chains per lane (2 = four lines per lane; LEAN only, k_stream_lean.h).
+template <int MODE, int HALVES, int THREADS, int NT = 2, bool LEAN = false, int GR = 1>
 __global__ void __launch_bounds__(THREADS)
 k_stream_multi(DevDfa d, MultiIo m) {
   static_assert(MODE == kSmLastStartEnd || MODE == kSmLastEnd || MODE == kSmFullStart ||
                 MODE == kSmFull, "the plain output modes only");
+  static_assert(!LEAN || MODE != kSmFull, "styFull without start has no bookkeeping to defer");
+  static_assert(GR == 1 || LEAN, "more than two chains per lane: the lean step only");
   constexpr uint32_t BLK = 64 * HALVES;
-  constexpr int CH = kStreamChains;
+  constexpr int CH = kStreamChains * GR;
   constexpr bool kAcc = MODE == kSmLastStartEnd || MODE == kSmLastEnd;
   constexpr bool kStart = MODE == kSmLastStartEnd || MODE == kSmFullStart;
   constexpr uint32_t LPT = uint32_t(THREADS) * CH;  // lines per tile
@@ -148,6 +153,7 @@ k_stream_multi(DevDfa d, MultiIo m) {
   int32_t *oRes = m.b[0].result;
   uint64_t *oStart = m.b[0].start, *oEnd = m.b[0].end;
   uint64_t oN = m.b[0].n;
+  const uint8_t *oData = m.b[0].data;  // LEAN: the pieces re-read at a line's end
   auto setWalkTile = [&]() {
     while (tile >= wkHi) {
       ++wkK;
@@ -157,14 +163,124 @@ k_stream_multi(DevDfa d, MultiIo m) {
       oStart = m.b[wkK].start;
       oEnd = m.b[wkK].end;
       oN = m.b[wkK].n;
+      if (LEAN) oData = m.b[wkK].data;
     }
   };
   setWalkTile();
 
   uint32_t s[CH], accS[CH], endv[CH], startv[CH];
   uint64_t mA[CH], mB[CH];
+  LeanRegs L[GR];
+  const uint32_t T8 = firstAccept << 8;
+
+  auto walkLean = [&](const BlockRegs<HALVES> (&blk)[CH]) {
+    if (r == 0) {
+#pragma unroll
+      for (int g = 0; g < GR; ++g) leanBegin(L[g], init);
+    }
+#pragma unroll
+    for (int g = 0; g < GR; ++g) leanPin(L[g]);
+    if (GR > 1) leanDrain();  // counted waits below: nothing else may be in flight on lgkmcnt
+#pragma unroll
+    for (int h = 0; h < HALVES; ++h) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint4 piece[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) piece[c] = blk[c].p[4 * h + q];
+        leanWalk16<kAcc, kStart, GR>(piece, L, T8, init);
+      }
+    }
+    if (GR > 1) leanDrain();  // every state register has landed before C++ code sees it
+    if (r + 1 == R) {
+      // the line ends: close the last piece's windows, then read the two remembered pieces again
+      // and walk them from their entry states with the exact step (k_stream.h) - 32 steps per
+      // line.  Loads and stores under this branch: the next block's wait sits them out once per
+      // LINE, which for the lines this form takes is once per >= 8 blocks.
+      const uint32_t lane = threadIdx.x & 63;
+      const uint64_t first = uint64_t(tile - wkLo) * LPT;
+#pragma unroll
+      for (int g = 0; g < GR; ++g) {
+        LeanRegs &G = L[g];
+        leanEnd(G, T8, init, kAcc, kStart);
+        uint64_t ln[2];
+        uint4 pa[2], ps[2];
+        uint32_t PA[2], PS[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          ln[c] = first + uint64_t(2 * g + c) * THREADS + threadIdx.x;
+          const uint64_t lc = ln[c] < oN ? ln[c] : oN - 1;
+          const uint8_t *base = oData + lc * lineLen;
+          PA[c] = G.recA[c] ? (G.recA[c] >> 8) - 1 : 0;
+          PS[c] = G.recS[c] ? (G.recS[c] >> 8) - 1 : 0;
+          if (kAcc) pa[c] = *reinterpret_cast<const uint4 *>(base + 16ull * PA[c]);
+          if (kStart) ps[c] = *reinterpret_cast<const uint4 *>(base + 16ull * PS[c]);
+        }
+        int32_t rr[2];
+        uint32_t en[2], sv[2];
+        if (kAcc) {
+          uint32_t s2[2];
+          StreamBook b2[2];
+          uint64_t u0[2] = {0, 0}, u1[2] = {0, 0};
+#pragma unroll
+          for (int c = 0; c < 2; ++c) { s2[c] = G.recA[c] & 0xffu; b2[c].acc = 0; b2[c].end = 0; b2[c].start = 0; }
+          streamWalk16<kSmLastEnd, 0>(pa, s2, b2, u0, u1, firstAccept, init);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            uint32_t acc = b2[c].acc, er = b2[c].end;
+            if (s2[c] >= firstAccept) { acc = s2[c]; er = 16; }
+            const bool hit = G.recA[c] != 0;
+            rr[c] = hit ? ldsRes[acc & 0xffu] : 0;
+            en[c] = hit ? 16u * PA[c] + er : 0u;
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            rr[c] = G.sX[c] >= firstAccept ? ldsRes[G.sX[c] & 0xffu] : 0;
+            en[c] = lineLen;
+          }
+        }
+        if (kStart) {
+          uint32_t s3[2];
+          StreamBook b3[2];
+          uint64_t w0[2], w1[2];
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            s3[c] = G.recS[c] & 0xffu;
+            b3[c].acc = 0; b3[c].end = 0; b3[c].start = 0;
+            w0[c] = __builtin_amdgcn_ballot_w64(s3[c] == init);  // no event "before" the piece
+            w1[c] = w0[c];
+          }
+          streamWalk16<kSmFullStart, 0>(ps, s3, b3, w0, w1, firstAccept, init);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            uint32_t pos = b3[c].start ? b3[c].start - 1 : 0;
+            if (((w0[c] >> lane) & 1) && s3[c] != init) pos = 15;
+            sv[c] = G.recS[c] ? 16u * PS[c] + pos : 0u;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          if (ln[c] < oN) {
+            __builtin_nontemporal_store(rr[c], oRes + ln[c]);
+            if (oEnd) __builtin_nontemporal_store(rr[c] ? uint64_t(en[c]) : uint64_t(0), oEnd + ln[c]);
+            if (kStart && oStart)
+              __builtin_nontemporal_store(rr[c] ? uint64_t(sv[c]) : uint64_t(0), oStart + ln[c]);
+          }
+        }
+      }
+    }
+    if (++r == R) {
+      r = 0;
+      tile += G;
+      if (tile < nTiles) setWalkTile();
+    }
+  };
 
   auto walkBlock = [&](const BlockRegs<HALVES> (&blk)[CH]) {
+    if constexpr (LEAN) {
+      walkLean(blk);
+    } else {
     if (r == 0) {
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
@@ -228,7 +344,7 @@ k_stream_multi(DevDfa d, MultiIo m) {
       int32_t *pr = report ? oRes + ln : reinterpret_cast<int32_t *>(d.sink);
       uint64_t *pe = report && oEnd ? oEnd + ln : reinterpret_cast<uint64_t *>(d.sink);
       uint64_t *ps = report && oStart ? oStart + ln : reinterpret_cast<uint64_t *>(d.sink);
-      if (NT & 2) {
+      if ((NT & 2) && R == 1) {  // (longer lines: the sink must stay a cached line, k_stream.h)
         __builtin_nontemporal_store(rr, pr);
         __builtin_nontemporal_store(rr ? uint64_t(en) : uint64_t(0), pe);
         if (kStart) __builtin_nontemporal_store(rr ? uint64_t(startv[c]) : uint64_t(0), ps);
@@ -243,6 +359,7 @@ k_stream_multi(DevDfa d, MultiIo m) {
       tile += G;
       if (tile < nTiles) setWalkTile();
     }
+    }  // !LEAN
   };
 
   // rotated by one block, as k_stream: both ways into the loop head end in "block requested, a
@@ -270,7 +387,7 @@ inline int multiLabInt(const char *name, int lo, int hi, int dflt) {
   return v < lo || v > hi ? dflt : v;
 }
 
-template <int MODE, int NT>
+template <int MODE, int NT, bool LEAN>
 hipError_t launchStreamMultiN(const DevDfa &d, const MultiIo &m, const LaunchCfg &cfg,
                               hipStream_t stream) {
   static const int wgs = multiLabInt("REDGPU_MULTI_WGS", 1, 2, 2);
@@ -279,22 +396,52 @@ hipError_t launchStreamMultiN(const DevDfa &d, const MultiIo &m, const LaunchCfg
   const uint32_t want = uint32_t(cfg.numCUs) * uint32_t(wide ? 1 : wgs);
   const uint32_t blocks = tiles < want ? tiles : want;
   if (wide)
-    hipLaunchKernelGGL((k_stream_multi<MODE, 2, kStreamThreads, NT>), dim3(blocks),
+    hipLaunchKernelGGL((k_stream_multi<MODE, 2, kStreamThreads, NT, LEAN>), dim3(blocks),
                        dim3(kStreamThreads), 0, stream, d, m);
   else
-    hipLaunchKernelGGL((k_stream_multi<MODE, 1, kStreamThreads, NT>), dim3(blocks),
+    hipLaunchKernelGGL((k_stream_multi<MODE, 1, kStreamThreads, NT, LEAN>), dim3(blocks),
                        dim3(kStreamThreads), 0, stream, d, m);
   return hipGetLastError();
+}
+
+// the lean step with FOUR lines per lane (two chain groups), 64-byte blocks, one workgroup per
+// CU: tiles of 2048 lines (the caller's MultiIo counts 1024-line tiles)
+template <int MODE>
+hipError_t launchStreamLean4(const DevDfa &d, const MultiIo &m, const LaunchCfg &cfg,
+                             hipStream_t stream) {
+  MultiIo m4 = m;
+  const uint64_t lpt = uint64_t(kStreamThreads) * kStreamChains * 2;
+  for (uint32_t k = 0; k < m.nb; ++k)
+    m4.tileStart[k + 1] = m4.tileStart[k] + uint32_t((m.b[k].n + lpt - 1) / lpt);
+  for (uint32_t k = m.nb; k < uint32_t(kMultiMax) + 1; ++k) m4.tileStart[k + 1] = m4.tileStart[m.nb];
+  const uint32_t tiles = m4.tileStart[m4.nb];
+  const uint32_t blocks = tiles < uint32_t(cfg.numCUs) ? tiles : uint32_t(cfg.numCUs);
+  hipLaunchKernelGGL((k_stream_multi<MODE, 1, kStreamThreads, 2, true, 2>), dim3(blocks),
+                     dim3(kStreamThreads), 0, stream, d, m4);
+  return hipGetLastError();
+}
+
+// REDGPU_F_FORCE_LEAN (or the lab's REDGPU_LEAN=1): lines from kLeanMinLine bytes up take the
+// deferred-bookkeeping step
+inline bool leanWanted(const MultiIo &m, const LaunchCfg &cfg) {
+  static const int lab = multiLabInt("REDGPU_LEAN", 0, 1, 0);
+  return (lab || cfg.forceLean) && m.lineLen >= kLeanMinLine && m.lineLen < (1u << 27);
 }
 
 template <int MODE>
 hipError_t launchStreamMultiT(const DevDfa &d, const MultiIo &m, const LaunchCfg &cfg,
                               hipStream_t stream) {
+  if constexpr (MODE != kSmFull) {
+    if (leanWanted(m, cfg)) {
+      if (cfg.leanChains4) return launchStreamLean4<MODE>(d, m, cfg, stream);
+      return launchStreamMultiN<MODE, 2, true>(d, m, cfg, stream);
+    }
+  }
   if constexpr (MODE == kSmLastStartEnd) {
     static const int nt = multiLabInt("REDGPU_MULTI_NT", 0, 3, 2);
-    if (nt == 0) return launchStreamMultiN<MODE, 0>(d, m, cfg, stream);
-    if (nt == 1) return launchStreamMultiN<MODE, 1>(d, m, cfg, stream);
-    if (nt == 3) return launchStreamMultiN<MODE, 3>(d, m, cfg, stream);
+    if (nt == 0) return launchStreamMultiN<MODE, 0, false>(d, m, cfg, stream);
+    if (nt == 1) return launchStreamMultiN<MODE, 1, false>(d, m, cfg, stream);
+    if (nt == 3) return launchStreamMultiN<MODE, 3, false>(d, m, cfg, stream);
   }
-  return launchStreamMultiN<MODE, 2>(d, m, cfg, stream);
+  return launchStreamMultiN<MODE, 2, false>(d, m, cfg, stream);
 }

@@ -72,6 +72,8 @@ struct LaunchCfg {
   int forceChunking = 0; // ... or whenever the shape allows, whatever the DFA (REDGPU_F_FORCE_CHUNKING)
   int forceEarly = 0;    // k_early for match over any LDS-resident table, whatever the DFA and
                          // the batch size (REDGPU_F_FORCE_EARLY; tests)
+  int forceLean = 0;     // long fixed-stride lines: k_stream_multi's lean step (REDGPU_F_FORCE_LEAN)
+  int leanChains4 = 0;   // ... with four lines per lane (REDGPU_F_LEAN_CHAINS_4)
   int streamChains = 0;  // fixed-stride hot path: 0 = by batch size, 2 = k_stream.h always,
                          // 3 / 4 = k_stream4.hip always (REDGPU_F_STREAM_CHAINS_*; tests, tuning)
 };
@@ -131,16 +133,27 @@ hipError_t launchSplitLines(const uint8_t *data, uint64_t len, uint8_t delim, ui
 hipError_t launchDiagRead(const void *data, uint64_t bytes, uint32_t *sink, int numCUs,
                           hipStream_t stream);
 
+// bench.py's read + write calibration: the streaming walk's memory side alone over nLines lines of
+// 64 bytes - each lane requests its line as k_stream does and stores one Outcome-shaped record
+// (int32 + 2 x uint64) per line; nLines is rounded down to a multiple of 1024.
+// lineBytes = 64, or a multiple of 128: the long-line request pattern, reads only.
+hipError_t launchDiagLines(const uint8_t *data, uint64_t nLines, uint32_t lineBytes, int32_t *res,
+                           uint64_t *st, uint64_t *en, uint32_t *sink, int numCUs,
+                           hipStream_t stream);
+
 // k_stream4.hip: the fixed-stride hot path with 3-4 chains per lane (mode = k_stream.h's
 // StreamMode value: Last+start+end 0, Last+end 1, Full+start 3, Full 4).
 bool stream4Eligible(const DevDfa &dfa, const Batch &b, const LaunchCfg &cfg);
 hipError_t launchStream4(int mode, const DevDfa &dfa, const Batch &b, const LaunchCfg &cfg,
                          hipStream_t stream);
 
-// Device scratch for the launches that need some (host_stage.cpp): a process-wide pool keyed by
-// (current device, stream), bounded, entries of a library-owned stream dropped with the stream.
+// Device scratch for the launches that need some (host_stage.cpp): a pool per HOST THREAD keyed
+// by (current device, stream) - the buffer carries state between the kernels of one call, so no
+// other thread may be handed it - bounded, freed at thread exit / redgpu_thread_release(),
+// entries of a library-owned stream dropped with the stream.  scratchEntries: all threads'.
 hipError_t scratchFor(hipStream_t stream, size_t bytes, void **out);
 void scratchDrop(int device, hipStream_t stream);
+void scratchReleaseThread();
 size_t scratchEntries();
 
 // bench.py's calibrations.  launchDiagLds: `rounds` x 64 dependent table lookups per chain, 4

@@ -1656,6 +1656,7 @@ k_leader_filter(DevDfa d, Batch b) {
 }
 
 #include "k_stream.h"
+#include "k_stream_lean.h"
 #include "k_stream_multi.h"
 #include "k_ragged.h"
 
@@ -2651,24 +2652,91 @@ k_split_scatter(const uint8_t *data, uint64_t len, uint32_t delim, const uint64_
 }
 
 // Calibration for bench.py ("the box's measured streaming-read ceiling from a
-// calibration kernel run in the same session"): reads `bytes` once with 16-byte loads, 4 in
-// flight per lane, and folds them into one word per workgroup so the loads cannot be dropped.
-__global__ void __launch_bounds__(256)
+// calibration kernel run in the same session"): reads `bytes` once with 16-byte loads, 8 in
+// flight per lane, and folds them into one word per wave so the loads cannot be dropped.
+__global__ void __launch_bounds__(512)
 k_diag_read(const uint4 *__restrict__ p, uint64_t n16, uint32_t *sink) {
-  const uint64_t step = uint64_t(gridDim.x) * 256;
-  uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
-  uint32_t acc = 0;
-  for (; i + 3 * step < n16; i += 4 * step) {
-    const uint4 a = p[i], b = p[i + step], c = p[i + 2 * step], d = p[i + 3 * step];
-    acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^
-           d.z ^ d.w;
+  // one 512-thread workgroup per CU, 8 non-temporal 16-byte loads in flight per lane: the
+  // fastest streaming read of the shapes tried on MI355X (scripts/lab/hbm_probe.hip: 6.8 TB/s;
+  // 256 threads x 8 workgroups per CU, this kernel's round-1 shape, 5.0-5.3)
+  typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+  const v4 *q = reinterpret_cast<const v4 *>(p);
+  const uint64_t step = uint64_t(gridDim.x) * 512;
+  uint64_t i = uint64_t(blockIdx.x) * 512 + threadIdx.x;
+  v4 acc = {0, 0, 0, 0};
+  for (; i + 7 * step < n16; i += 8 * step) {
+    v4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(q + i + k * step);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc ^= v[k];
   }
-  for (; i < n16; i += step) {
-    const uint4 a = p[i];
-    acc ^= a.x ^ a.y ^ a.z ^ a.w;
+  for (; i < n16; i += step) acc ^= q[i];
+  uint32_t a = acc.x ^ acc.y ^ acc.z ^ acc.w;
+  for (int o = 32; o; o >>= 1) a ^= __shfl_xor(a, o);
+  if ((threadIdx.x & 63) == 0 && a == 0x9e3779b9u) atomicAdd(sink, 1u);
+}
+
+// The memory side of the streaming walk over 64-byte lines with nothing else: every lane requests
+// its line as k_stream does (4 x 16 bytes back to back, 2 lines per lane) and stores an
+// Outcome-shaped record per line (int32 + 2 x uint64, non-temporal) - 64 B read + 20 B written
+// per line.  What HBM gives this mix is the roof of configs[1]'s shape (bench.py reports it).
+__global__ void __launch_bounds__(512)
+k_diag_lines(const uint8_t *__restrict__ data, uint64_t nLines, int32_t *res, uint64_t *st,
+             uint64_t *en, uint32_t *sink) {
+  typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+  const uint64_t tiles = nLines / 1024;
+  v4 acc = {0, 0, 0, 0};
+  for (uint64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    v4 v[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const uint64_t ln = t * 1024 + uint64_t(c) * 512 + threadIdx.x;
+        v[c][k] = reinterpret_cast<const v4 *>(data + ln * 64)[k];
+      }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const uint64_t ln = t * 1024 + uint64_t(c) * 512 + threadIdx.x;
+      const v4 x = v[c][0] ^ v[c][1] ^ v[c][2] ^ v[c][3];
+      acc ^= x;
+      __builtin_nontemporal_store(int32_t(x.x), res + ln);
+      __builtin_nontemporal_store(uint64_t(x.y), st + ln);
+      __builtin_nontemporal_store(uint64_t(x.z), en + ln);
+    }
   }
-  for (int o = 32; o; o >>= 1) acc ^= __shfl_xor(acc, o);
-  if ((threadIdx.x & 63) == 0 && acc == 0x9e3779b9u) atomicAdd(sink, 1u);
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) atomicAdd(sink, 1u);
+}
+
+// ... and over LONG lines (a multiple of 128 bytes): a lane requests one whole cache line of each
+// of its two lines at a time, as k_stream's 128-byte form does - the 64 lanes of a wave touch 64
+// cache lines that lie a line length apart.  No stores (one Outcome per line is noise here).
+// MI355X gives this pattern 5.3 TB/s at 4 KiB lines, 3.0 at 16 KiB, 1.7 at 64 KiB, where a
+// coalesced read of the same bytes gets 6.4 (scripts/lab/hbm_probe.hip).
+__global__ void __launch_bounds__(512)
+k_diag_long(const uint8_t *__restrict__ data, uint64_t nLines, uint32_t lineBytes, uint32_t *sink) {
+  typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+  const uint64_t tiles = nLines / 1024;
+  const uint32_t R = lineBytes / 128;
+  v4 acc = {0, 0, 0, 0};
+  for (uint64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    for (uint32_t r = 0; r < R; ++r) {
+      v4 v[2][8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const uint64_t ln = t * 1024 + uint64_t(c) * 512 + threadIdx.x;
+          v[c][k] = reinterpret_cast<const v4 *>(data + ln * lineBytes + uint64_t(r) * 128)[k];
+        }
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc ^= v[c][k];
+    }
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) atomicAdd(sink, 1u);
 }
 
 template <class K>
@@ -3098,8 +3166,10 @@ hipError_t launchFixedFamily(const DevDfa &d, const Batch &b, int verb, int styl
     hipError_t e;
     Batch sb = b;
     if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
+    static const int labLean = multiLabInt("REDGPU_LEAN", 0, 1, 0);
     static const int labSingle = multiLabInt("REDGPU_MULTI_SINGLE", 0, 1, 0);
-    if (labSingle) {  // lab: a single batch through the multi-batch kernel
+    if (cfg.forceLean || labLean || labSingle) {
+      // opt-in: k_stream_multi (its deferred-bookkeeping form for long lines) for a batch on its own
       uint32_t taken = 0;
       e = launchStreamBatches(d, &b, 1, verb, style, doLeader, cfg, stream, kernelName, &taken);
       if (e != hipSuccess || taken) return e;
@@ -3205,7 +3275,8 @@ hipError_t launchStreamBatches(const DevDfa &d, const Batch *bs, uint32_t nb, in
     return hipSuccess;
   auto plain = [&](const Batch &b) {
     // (few long lines over a forgetful DFA are launchFixedFamily's speculative chunks)
-    const bool chunky = fewLines(b, cfg) && d.forgetful && !cfg.noChunking && b.stride >= 4096;
+    const bool chunky = fewLines(b, cfg) && d.forgetful && !cfg.noChunking && b.stride >= 4096 &&
+                        !cfg.forceLean;
     return !b.offsets && b.stride >= 64 && b.stride % 64 == 0 && b.stride < (1ull << 31) &&
            (reinterpret_cast<uintptr_t>(b.data) % 16) == 0 && b.n > 0 && !chunky &&
            b.n < (1ull << 40) && !stream4Eligible(d, b, cfg);
@@ -3228,15 +3299,20 @@ hipError_t launchStreamBatches(const DevDfa &d, const Batch *bs, uint32_t nb, in
     ++m.nb;
   }
   // (fewer tiles than CUs in all: the single-batch launches spread such lines better)
-  static const int labSingle = multiLabInt("REDGPU_MULTI_SINGLE", 0, 1, 0);  // lab: nb = 1 too
-  if (m.nb < (labSingle ? 1u : 2u) || m.tileStart[m.nb] < uint32_t(cfg.numCUs)) return hipSuccess;
+  // (one batch on its own keeps k_stream - unless its lines are long enough for the lean step,
+  // or the lab says otherwise: REDGPU_MULTI_SINGLE=1)
+  static const int labSingle = multiLabInt("REDGPU_MULTI_SINGLE", 0, 1, 0);
+  const bool lean = leanWanted(m, cfg) && !(style == kStyFull && !wantStart);
+  if (m.nb < ((labSingle || lean) ? 1u : 2u) ||
+      (m.tileStart[m.nb] < uint32_t(cfg.numCUs) && !(lean && cfg.forceLean)))
+    return hipSuccess;
   for (uint32_t k = m.nb; k < uint32_t(kMultiMax) + 1; ++k) m.tileStart[k + 1] = m.tileStart[m.nb];
   hipError_t e;
   if (style == kStyLast) {
-    if (wantStart) { *kernelName = "k_stream_multi<last,start,end>"; e = launchStreamMultiT<kSmLastStartEnd>(d, m, cfg, stream); }
-    else { *kernelName = "k_stream_multi<last,end>"; e = launchStreamMultiT<kSmLastEnd>(d, m, cfg, stream); }
+    if (wantStart) { *kernelName = lean ? "k_stream_multi<last,start,end,lean>" : "k_stream_multi<last,start,end>"; e = launchStreamMultiT<kSmLastStartEnd>(d, m, cfg, stream); }
+    else { *kernelName = lean ? "k_stream_multi<last,end,lean>" : "k_stream_multi<last,end>"; e = launchStreamMultiT<kSmLastEnd>(d, m, cfg, stream); }
   } else {
-    if (wantStart) { *kernelName = "k_stream_multi<full,start>"; e = launchStreamMultiT<kSmFullStart>(d, m, cfg, stream); }
+    if (wantStart) { *kernelName = lean ? "k_stream_multi<full,start,lean>" : "k_stream_multi<full,start>"; e = launchStreamMultiT<kSmFullStart>(d, m, cfg, stream); }
     else { *kernelName = "k_stream_multi<full>"; e = launchStreamMultiT<kSmFull>(d, m, cfg, stream); }
   }
   if (e != hipSuccess) return e;
@@ -3450,8 +3526,22 @@ hipError_t launchSplitLines(const uint8_t *data, uint64_t len, uint8_t delim, ui
 hipError_t launchDiagRead(const void *data, uint64_t bytes, uint32_t *sink, int numCUs,
                           hipStream_t stream) {
   if (bytes < 16) return hipSuccess;
-  hipLaunchKernelGGL(k_diag_read, dim3(uint32_t(numCUs) * 8), dim3(256), 0, stream,
+  hipLaunchKernelGGL(k_diag_read, dim3(uint32_t(numCUs)), dim3(512), 0, stream,
                      static_cast<const uint4 *>(data), bytes / 16, sink);
+  return hipGetLastError();
+}
+
+hipError_t launchDiagLines(const uint8_t *data, uint64_t nLines, uint32_t lineBytes, int32_t *res,
+                           uint64_t *st, uint64_t *en, uint32_t *sink, int numCUs,
+                           hipStream_t stream) {
+  if (nLines < 1024) return hipSuccess;
+  if (lineBytes != 64) {
+    hipLaunchKernelGGL(k_diag_long, dim3(uint32_t(numCUs)), dim3(512), 0, stream, data, nLines,
+                       lineBytes, sink);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(k_diag_lines, dim3(uint32_t(numCUs)), dim3(512), 0, stream, data, nLines, res,
+                     st, en, sink);
   return hipGetLastError();
 }
 

@@ -37,6 +37,8 @@ LaunchCfg cfgOf(const redgpu_dfa *dfa, uint32_t extraFlags = 0) {
                    (dfa->flags & REDGPU_F_NO_CHUNKING) ? 1 : 0,
                    (dfa->flags & REDGPU_F_FORCE_CHUNKING) ? 1 : 0,
                    (dfa->flags & REDGPU_F_FORCE_EARLY) ? 1 : 0,
+                   (dfa->flags & REDGPU_F_FORCE_LEAN) ? 1 : 0,
+                   (dfa->flags & REDGPU_F_LEAN_CHAINS_4) ? 1 : 0,
                    (dfa->flags & REDGPU_F_STREAM_CHAINS_2) ? 2
                    : (dfa->flags & REDGPU_F_STREAM_CHAINS_4) ? 4 : 0};
 }
@@ -817,6 +819,25 @@ int redgpu_diag_read_dev(const redgpu_dfa *dfa, const void *data, uint64_t bytes
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   hipError_t e = launchDiagRead(data, bytes, sink, dfa->numCUs, static_cast<hipStream_t>(stream));
   tlsKernel = "k_diag_read";
+  if (e != hipSuccess) return failHip(e, "kernel launch");
+  return REDGPU_OK;
+}
+
+int redgpu_diag_lines_dev(const redgpu_dfa *dfa, const uint8_t *data, uint64_t n_lines,
+                          uint64_t line_bytes, int32_t *result, uint64_t *start, uint64_t *end,
+                          uint32_t *sink, void *stream) {
+  if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
+  if (dfa->im->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (line_bytes != 64 && (line_bytes % 128 || line_bytes == 0 || line_bytes >= (1ull << 31)))
+    return fail(REDGPU_EAPI, "line_bytes must be 64 or a multiple of 128");
+  if (!data || !sink || (line_bytes == 64 && (!result || !start || !end)))
+    return fail(REDGPU_EAPI, "null buffer");
+  if (reinterpret_cast<uintptr_t>(data) % 16) return fail(REDGPU_EAPI, "buffer not 16-byte aligned");
+  DeviceScope scope(dfa->im->device);
+  if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  hipError_t e = launchDiagLines(data, n_lines, uint32_t(line_bytes), result, start, end, sink,
+                                 dfa->numCUs, static_cast<hipStream_t>(stream));
+  tlsKernel = "k_diag_lines";
   if (e != hipSuccess) return failHip(e, "kernel launch");
   return REDGPU_OK;
 }

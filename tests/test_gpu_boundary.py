@@ -66,8 +66,42 @@ def test_eight_host_threads_share_one_handle():
     for th in threads:
         th.join()
     assert not errors, errors
-    # scratch is pooled per (device, stream), bounded, and the threads' own streams took theirs along
+    # scratch is pooled per thread and (device, stream), bounded, and released with the thread
     assert _lib.lib().redgpu_scratch_entries() <= 64
+
+
+def test_threads_share_one_stream_for_ragged_dev_calls():
+    """the ragged launches are multi-kernel sequences that carry state in a scratch
+    buffer (tail pad, length buckets).  Two host threads issuing _dev calls on the SAME stream (the
+    default one) with batches of different sizes must not see each other's scratch - it is kept
+    per thread - whatever the interleaving; every result against the oracle."""
+    import torch
+    blob = load_dfa("uri")
+    exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
+    sets = []
+    for t, n in enumerate((3000, 70000, 500, 260000)):
+        d, o = W.ragged_lines(n, 1, 300 if t % 2 else 90, 31 + t, heads=[W.URI_PLANT], head_every=3)
+        exp = cpu.batch("match", 4, 0, d, offsets=o, threads=4)
+        sets.append((torch.from_numpy(d).cuda(), torch.from_numpy(o.astype(np.int64)).cuda(), exp))
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(25):
+                dd, do, exp = sets[(t + rep) % len(sets)]
+                r, s, e = one_amd.match_batch(exe, dd, 4, 0, offsets=do)   # torch's default stream
+                got = (r.cpu().numpy(), s.cpu().numpy(), e.cpu().numpy())
+                assert _eq(got, exp), ("thread", t, "rep", rep, one_amd.last_kernel())
+        except BaseException as ex:  # noqa: BLE001
+            errors.append(repr(ex))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
 
 
 def test_short_lived_threads_do_not_accumulate_scratch():

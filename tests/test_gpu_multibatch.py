@@ -150,3 +150,54 @@ def test_full_size_config1_twenty_batches_one_launch():
     torch.cuda.synchronize()
     for i in range(steps):
         _same(outs[i], exps[i % nbuf], ("step", i))
+
+
+LEAN_SHAPES = [(512, 70000), (4096, 9000), (1024, 33000), (576, 60001), (8192, 4097)]
+
+
+@pytest.mark.parametrize("chains", [2, 4])
+@pytest.mark.parametrize("stride,n", LEAN_SHAPES)
+@pytest.mark.parametrize("name", ["syn256", "uri", "dotstar_err", "newyork"])
+def test_lean_step_long_lines_vs_oracle(name, stride, n, chains):
+    """REDGPU_F_FORCE_LEAN: lines of 512 bytes and more take k_stream_multi's deferred-bookkeeping
+    step (k_stream_lean.h), two or four lines per lane: per byte it only notes in which 16-byte piece the last accept and the
+    last "left the initial state" lie, the two pieces are re-walked exactly at the line's end.
+    Styles Last / Full of match and check, with and without start, with the leader, against the
+    oracle (Matcher.h:413-495); strides that are / are not multiples of 128."""
+    import torch
+    blob = load_dfa(name)
+    exe = one_amd.Executable(blob, no_chunking=True, force_lean=True, lean_chains=chains)
+    cpu = O.CpuOracle(blob)
+    if name == "syn256":
+        h = W.fixed_lines(n, stride, stride + n, alphabet=False)
+    else:
+        plant = {"uri": W.URI_PLANT, "dotstar_err": b"an error", "newyork": b"New York"}[name]
+        h = W.fixed_lines(n, stride, stride + n, plant=plant, plant_every=3, plant_at=stride - 200)
+        v = h.reshape(n, stride)
+        v[1::5, :len(plant)] = np.frombuffer(plant, dtype=np.uint8)          # at the line's start
+        v[2::7, stride - len(plant):] = np.frombuffer(plant, dtype=np.uint8)  # ... and at its very end
+        v[3::11, 15:15 + len(plant)] = np.frombuffer(plant, dtype=np.uint8)   # across a piece border
+    d = torch.from_numpy(h).cuda()
+    for si in (4, 5):
+        for lead in (0, 1):
+            exp = cpu.batch("match", si, lead, h, stride=stride, n=n, threads=8)
+            got = one_amd.match_batch(exe, d, si, lead, stride=stride, n=n)
+            k = one_amd.last_kernel()
+            assert "lean" in k, k
+            torch.cuda.synchronize()
+            _same(got, exp, (name, stride, si, lead, k))
+            if si == 4:
+                got = one_amd.match_batch(exe, d, si, lead, stride=stride, n=n, want_start=False)
+                assert "lean" in one_amd.last_kernel()
+                torch.cuda.synchronize()
+                _same(got, (exp[0], None, exp[2]), (name, stride, si, lead, "no start"))
+        cr = cpu.batch("check", si, 0, h, stride=stride, n=n, threads=8)[0]
+        r = one_amd.check_batch(exe, d, si, 0, stride=stride, n=n)
+        torch.cuda.synchronize()
+        assert np.array_equal(r.cpu().numpy(), cr), (name, stride, si, one_amd.last_kernel())
+    # two such batches in one call
+    outs = one_amd.match_batches(exe, [d, d], 4, 0, stride=stride)
+    torch.cuda.synchronize()
+    exp = cpu.batch("match", 4, 0, h, stride=stride, n=n, threads=8)
+    _same(outs[0], exp, "two batches, first")
+    _same(outs[1], exp, "two batches, second")

@@ -286,10 +286,43 @@ def cpu_baseline(args, wl, oracle):
     t1 = time.perf_counter()
     eng.batch("match", "last", wl.lead, data, threads=1, **kw)
     one = nbytes / (time.perf_counter() - t1) / 1e9
-    return {"value": round(gbs, 3), "unit": "GB/s", "cores": cores, "kind": kind,
-            "sample": "%d passes over %s, match<styLast,%s>, %d threads" %
-                      (passes, what, "true" if wl.lead else "false", cores),
-            "single_thread_GBps": round(one, 3)}
+    model, phys, logical = cpu_identity()
+    out = {"value": round(gbs, 3), "unit": "GB/s", "cores": cores, "kind": kind,
+           "sample": "%d passes over %s, match<styLast,%s>, %d threads" %
+                     (passes, what, "true" if wl.lead else "false", cores),
+           "single_thread_GBps": round(one, 3),
+           "cpu_model": model, "physical_cores_of_host": phys, "logical_cpus_of_host": logical,
+           "threads_used": cores,
+           "speedup_over_one_thread": round(gbs / one, 1) if one else None,
+           "scaling_note": ("threads are pinned to nothing and capped at this process's CPU affinity "
+                            "(min(affinity, 64)); the reference's matcher is one dependent L1 load per "
+                            "byte (Proxy.h:143-147), so SMT siblings share a core's load port and add "
+                            "little, each pass spawns and joins its threads (a 64 MiB pass lasts "
+                            "~16 ms at this rate), and the box's other tenants share the sockets - "
+                            "which is why N threads give less than N x one thread here although the "
+                            "matcher itself is lock-free (doc/Performance.md:81-84)")}
+    return out
+
+
+def cpu_identity():
+    """CPU model name, physical cores and logical CPUs of the host (from /proc/cpuinfo)."""
+    model, phys, logical = "unknown", None, os.cpu_count()
+    try:
+        cores = set()
+        cur_phys = None
+        for ln in open("/proc/cpuinfo"):
+            k, _, v = ln.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model == "unknown":
+                model = v
+            elif k == "physical id":
+                cur_phys = v
+            elif k == "core id":
+                cores.add((cur_phys, v))
+        phys = len(cores) or None
+    except OSError:
+        pass
+    return model, phys, logical
 
 
 # ------------------------------------------------------------------------------------------------
@@ -759,6 +792,21 @@ def main():
             l.redgpu_match_batch_dev(*wl.call_tuple(0, cur_stream))
             torch.cuda.synchronize()
             calib["scan_instant_agrees_with_match"] = bool(((sres != 0) == (wl.outs[0][0] != 0)).all())
+        # (c6) the L2 gather roof, measured: dependent 2-byte gathers over a 2 MiB table in L2, no
+        # input side (replaces the literal derived from L2's nominal 34.5 TB/s)
+        if info["table_kind"] in (4, 5):
+            ltab = torch.randint(0, 65536, (1 << 20,), device="cuda", dtype=torch.int32).to(torch.int16)
+            for _ in range(2):
+                l.redgpu_diag_l2_dev(wl.exe._h, ltab.data_ptr(), 4096, sink.data_ptr(), C.byref(lookups), cur_stream)
+            c0.record()
+            for _ in range(3):
+                l.redgpu_diag_l2_dev(wl.exe._h, ltab.data_ptr(), 4096, sink.data_ptr(), C.byref(lookups), cur_stream)
+            c1.record()
+            torch.cuda.synchronize()
+            calib["l2_gather_roof_Glookups"] = round(3 * lookups.value / (c0.elapsed_time(c1) * 1e-3) / 1e9, 1)
+            calib["l2_gather_roof_how"] = ("k_diag_l2: %d dependent 2-byte gathers per launch over a 2 MiB table "
+                                           "resident in L2, 2 chains/lane x 2048 lanes/CU, no input traffic; "
+                                           "1 gather = 1 input byte of a table-in-L2 walk" % lookups.value)
         # (d) bytes the walk actually reads (early-exit DFAs)
         if info["early_death"] or wl.ragged:
             w = torch.zeros(1, dtype=torch.int64, device="cuda")
@@ -788,7 +836,10 @@ def main():
                            "per the gfx950 note + WRITE_SIZE), NOT measured by this run" %
                            os.path.relpath(pmc_path, ROOT))
             break
-    peak = L2_PEAK_GLOOKUPS if l2_bound else HBM_PEAK_GBS
+    # the L2-bound config is priced against the gather roof measured in this run (k_diag_l2); the
+    # figure derived from the guide's nominal L2 bandwidth is kept beside it
+    l2_peak = calib.get("l2_gather_roof_Glookups") or L2_PEAK_GLOOKUPS
+    peak = l2_peak if l2_bound else HBM_PEAK_GBS
     roofline = {
         "bound": "l2-gather" if l2_bound else "hbm",
         "achieved": round(achieved, 1),
@@ -824,9 +875,12 @@ def main():
         roofline["traffic_source"] = traffic_src
     if l2_bound:
         roofline["hbm_frac"] = round(wl.in_bytes * batches_per_launch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        roofline["peak_source"] = ("l2_gather_roof_Glookups, measured in this run" if
+                                   calib.get("l2_gather_roof_Glookups") else "nominal")
+        roofline["l2_nominal_request_roof_Glookups"] = L2_PEAK_GLOOKUPS
         roofline["bound_note"] = ("one dependent gather of the 2 MiB class table per input byte; it "
-                                  "lives in L2 (4 MiB per XCD), whose request rate - 34.5 TB/s / "
-                                  "128 B - caps any one-lookup-per-byte walk at 269.5 GB/s of input")
+                                  "lives in L2 (4 MiB per XCD): the walk cannot issue more gathers "
+                                  "than L2 serves (nominally 34.5 TB/s / 128 B = 269.5 G requests/s)")
     if walked is not None:
         roofline["bytes_walked_per_launch"] = walked
         roofline["walked_frac_of_input"] = round(walked / max(1, wl.in_bytes), 4)

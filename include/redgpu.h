@@ -372,6 +372,14 @@ int redgpu_diag_lds_dev(const redgpu_dfa *dfa, uint32_t rounds, uint32_t *sink, 
 int redgpu_diag_lines_dev(const redgpu_dfa *dfa, const uint8_t *data, uint64_t n_lines,
                           uint64_t line_bytes, int32_t *result, uint64_t *start, uint64_t *end,
                           uint32_t *sink, void *stream);
+/*  - redgpu_diag_l2_dev: the gather rate of a table that lives in L2 - `rounds` DEPENDENT 2-byte
+ *    gathers per chain (the next index is computed from the value just read, as a walk's next
+ *    state is) over `table`, 2^20 uint16 of device memory (2 MiB, any contents), 2 chains per lane,
+ *    2048 lanes per CU, no input side: the roof of a one-lookup-per-byte walk over a
+ *    REDGPU_TAB_GLOBAL_* DFA (SYN-4K), measured in the run instead of derived from L2's nominal
+ *    bandwidth.  *lookups (host) = gathers performed. */
+int redgpu_diag_l2_dev(const redgpu_dfa *dfa, const uint16_t *table, uint32_t rounds, uint32_t *sink,
+                       uint64_t *lookups, void *stream);
 int redgpu_diag_walked_dev(const redgpu_dfa *dfa, int do_leader, const uint8_t *data,
                            const uint64_t *offsets, uint64_t stride, uint64_t n, uint64_t *walked,
                            void *stream);
@@ -402,14 +410,24 @@ uint64_t redgpu_scratch_entries(void);
  *                            n[g] lines; ragged offsets are relative to data[g]).  Every device
  *                            scans on a stream of its own; results are packed into compact
  *                            records (result in 1/2/4 bytes by the DFA's largest result, start /
- *                            end in 1/2/4/8 bytes by the longest possible position), moved to the
- *                            ROOT device (devices[0]) over xGMI - REDGPU_GATHER_PEER: peer copies,
+ *                            end in 1/2/4 bytes by the stride, 4 bytes for ragged lines - 8 on a
+ *                            handle made with REDGPU_F_FORCE_GENERIC), moved to the ROOT device
+ *                            (devices[0]) over xGMI - REDGPU_GATHER_PEER: peer copies,
  *                            REDGPU_GATHER_RCCL: ncclSend / ncclRecv (librccl.so loaded on first
  *                            use) - and widened there into result / start / end (memory of the
- *                            root device, sum(n[]) entries, shard order).  Asynchronous: the
- *                            results are complete when `root_stream` (a stream of the root device,
- *                            NULL = its null stream) has reached this point.  One such call at a
- *                            time per group (serialised internally). */
+ *                            root device, sum(n[]) entries, shard order).  Asynchronous, no host
+ *                            synchronisation: the results are complete when `root_stream` (a
+ *                            stream of the root device, NULL = its null stream) has reached this
+ *                            point.  shard_streams[g] (a stream of device g, or shard_streams ==
+ *                            NULL): the stream on which shard g's inputs were produced and on
+ *                            which the caller will touch them next - the shard's scan starts where
+ *                            that stream stands at the call, and the stream in turn waits until
+ *                            the scan has read the shard, so inputs may be reused or freed
+ *                            stream-ordered.  With shard_streams == NULL every input must be
+ *                            complete at the call and stay untouched until root_stream has passed
+ *                            it.  One such call at a time per group (serialised internally).
+ *                            The peer / RCCL paths between DISTINCT devices have not run on
+ *                            hardware yet (single-GPU boxes only): see INTEGRATION.md. */
 typedef struct redgpu_group redgpu_group;
 #define REDGPU_VERB_CHECK  0
 #define REDGPU_VERB_MATCH  1
@@ -430,7 +448,8 @@ int redgpu_group_batch(const redgpu_group *group, int verb, int style, int do_le
 int redgpu_group_batch_dev(redgpu_group *group, int verb, int style, int do_leader,
                            const uint8_t *const *data, const uint64_t *const *offsets,
                            uint64_t stride, const uint64_t *n, int32_t *result, uint64_t *start,
-                           uint64_t *end, int gather, void *root_stream);
+                           uint64_t *end, int gather, void *const *shard_streams,
+                           void *root_stream);
 
 /* The compact record format of redgpu_group_batch_dev, for callers that move the results
  * themselves (one process per GPU over torch.distributed / RCCL: one_amd/sharding.py).  A

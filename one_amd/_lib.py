@@ -150,6 +150,8 @@ def lib() -> C.CDLL:
         l.redgpu_diag_lds_dev.argtypes = [vp, C.c_uint32, vp, C.POINTER(u64), vp]
         l.redgpu_diag_lines_dev.restype = C.c_int
         l.redgpu_diag_lines_dev.argtypes = [vp, vp, u64, u64, vp, vp, vp, vp, vp]
+        l.redgpu_diag_l2_dev.restype = C.c_int
+        l.redgpu_diag_l2_dev.argtypes = [vp, vp, C.c_uint32, vp, C.POINTER(u64), vp]
         l.redgpu_diag_walked_dev.restype = C.c_int
         l.redgpu_diag_walked_dev.argtypes = [vp, i32, vp, vp, u64, u64, vp, vp]
         l.redgpu_thread_release.restype = None
@@ -169,7 +171,7 @@ def lib() -> C.CDLL:
         l.redgpu_group_batch.argtypes = [vp, i32, i32, i32, vp, vp, u64, u64, vp, vp, vp]
         l.redgpu_group_batch_dev.restype = C.c_int
         l.redgpu_group_batch_dev.argtypes = [vp, i32, i32, i32, vp, vp, u64, vp, vp, vp, vp, i32,
-                                             vp]
+                                             vp, vp]
         l.redgpu_records_bytes.restype = u64
         l.redgpu_records_bytes.argtypes = [u64, i32, i32, i32]
         l.redgpu_records_pack_dev.restype = C.c_int

@@ -65,22 +65,6 @@ k_unpack(const uint8_t *rec, uint64_t n, int rw, int pw, int32_t *res, uint64_t 
   }
 }
 
-// longest line of a ragged shard (positions never exceed it)
-__global__ void __launch_bounds__(256)
-k_maxlen(const uint64_t *offsets, uint64_t n, unsigned long long *out) {
-  unsigned long long m = 0;
-  const uint64_t step = uint64_t(gridDim.x) * 256;
-  for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += step) {
-    const unsigned long long l = offsets[i + 1] - offsets[i];
-    m = l > m ? l : m;
-  }
-  for (int o = 32; o; o >>= 1) {
-    const unsigned long long v = __shfl_xor(m, o);
-    m = v > m ? v : m;
-  }
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
-}
-
 int widthFor(uint64_t maxValue) {
   return maxValue <= 0xffull ? 1 : maxValue <= 0xffffull ? 2 : maxValue <= 0xffffffffull ? 4 : 8;
 }
@@ -133,18 +117,21 @@ struct Member {
   int device = -1;
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;
+  hipEvent_t ready = nullptr;  // "the shard's producer stream has reached the call"
   // grow-only working buffers of the device form
   int32_t *res = nullptr;
   uint64_t *start = nullptr, *end = nullptr;
   uint8_t *rec = nullptr;
-  unsigned long long *maxLen = nullptr;
   size_t resCap = 0, startCap = 0, endCap = 0, recCap = 0;
   void *comm = nullptr;  // ncclComm_t
 };
 
 hipError_t grow(void **p, size_t *cap, size_t bytes) {
   if (*p && *cap >= bytes) return hipSuccess;
-  if (*p) (void)hipFree(*p);
+  if (*p) {
+    (void)hipDeviceSynchronize();  // an earlier call's pack / copy may still be reading it
+    (void)hipFree(*p);
+  }
   *p = nullptr;
   *cap = 0;
   const size_t want = bytes + bytes / 4 + 256;
@@ -234,6 +221,7 @@ int redgpu_group_create(const void *reda, size_t len, const redgpu_opts *opts,
     hipError_t e = scope.err;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->m[i].stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->m[i].done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->m[i].ready, hipEventDisableTiming);
     if (e == hipSuccess && i == 0) e = hipEventCreateWithFlags(&g->consumed, hipEventDisableTiming);
     if (e != hipSuccess) {
       redgpu_group *raw = g.release();
@@ -270,13 +258,14 @@ void redgpu_group_destroy(redgpu_group *g) {
       DeviceScope scope(mb.device);
       if (mb.stream) (void)hipStreamSynchronize(mb.stream);
       if (mb.comm && rccl().ok) (void)rccl().CommDestroy(mb.comm);
-      for (void *p : {(void *)mb.res, (void *)mb.start, (void *)mb.end, (void *)mb.rec, (void *)mb.maxLen})
+      for (void *p : {(void *)mb.res, (void *)mb.start, (void *)mb.end, (void *)mb.rec})
         if (p) (void)hipFree(p);
       if (mb.stream) {
         scratchDrop(mb.device, mb.stream);
         (void)hipStreamDestroy(mb.stream);
       }
       if (mb.done) (void)hipEventDestroy(mb.done);
+      if (mb.ready) (void)hipEventDestroy(mb.ready);
     }
     if (mb.dfa) redgpu_dfa_destroy(mb.dfa);
   }
@@ -422,7 +411,8 @@ int redgpu_group_batch(const redgpu_group *g, int verb, int style, int do_leader
 int redgpu_group_batch_dev(redgpu_group *g, int verb, int style, int do_leader,
                            const uint8_t *const *data, const uint64_t *const *offsets,
                            uint64_t stride, const uint64_t *n, int32_t *result, uint64_t *start,
-                           uint64_t *end, int gather, void *root_stream) {
+                           uint64_t *end, int gather, void *const *shard_streams,
+                           void *root_stream) {
   if (!g) return fail(REDGPU_EAPI, "null group handle");
   if (verb < REDGPU_VERB_CHECK || verb > REDGPU_VERB_SEARCH) return fail(REDGPU_EAPI, "bad verb");
   if (!data || !n) return fail(REDGPU_EAPI, "null shard arrays");
@@ -467,6 +457,11 @@ int redgpu_group_batch_dev(redgpu_group *g, int verb, int style, int do_leader,
     if (start) HIP_TRY(grow(reinterpret_cast<void **>(&mb.start), &mb.startCap, n[k] * 8), "hipMalloc shard start");
     if (end) HIP_TRY(grow(reinterpret_cast<void **>(&mb.end), &mb.endCap, n[k] * 8), "hipMalloc shard end");
     const uint64_t *off = offsets ? offsets[k] : nullptr;
+    if (shard_streams) {
+      // the shard's inputs are complete where its producer stream stands now: the scan waits there
+      HIP_TRY(hipEventRecord(mb.ready, static_cast<hipStream_t>(shard_streams[k])), "hipEventRecord");
+      HIP_TRY(hipStreamWaitEvent(mb.stream, mb.ready, 0), "hipStreamWaitEvent");
+    }
     int rc;
     switch (verb) {
     case REDGPU_VERB_CHECK: rc = redgpu_check_batch_dev(mb.dfa, style, do_leader, data[k], off, stride, n[k], mb.res, mb.stream); break;
@@ -480,24 +475,18 @@ int redgpu_group_batch_dev(redgpu_group *g, int verb, int style, int do_leader,
                                   start ? mb.start : nullptr, end ? mb.end : nullptr, mb.stream);
     }
     if (rc != REDGPU_OK) return rc;
-    if (positions && off) {
-      if (!mb.maxLen) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&mb.maxLen), 8), "hipMalloc");
-      HIP_TRY(hipMemsetAsync(mb.maxLen, 0, 8, mb.stream), "hipMemsetAsync");
-      hipLaunchKernelGGL(k_maxlen, dim3(256), dim3(256), 0, mb.stream, off, n[k], mb.maxLen);
-    }
   }
-  // 2. record widths: positions never exceed the longest line
+  // 2. record widths: positions never exceed the longest line.  Fixed stride: that is the stride.
+  // Ragged lines: nothing on the host knows the offsets, and reading the longest line back would
+  // put a host synchronisation into a call that promises none (round 2 did) - 4-byte positions,
+  // which is what the block-wise kernels compute in anyway (a handle made with
+  // REDGPU_F_FORCE_GENERIC, the only way to lines of 4 GiB and more, gets 8).
   for (size_t k = 0; k < G; ++k) {
     if (!n[k]) continue;
     Member &mb = g->m[k];
     uint64_t maxPos = stride;
-    if (positions && offsets && offsets[k]) {
-      DeviceScope scope(mb.device);
-      unsigned long long v = 0;
-      HIP_TRY(hipMemcpyAsync(&v, mb.maxLen, 8, hipMemcpyDeviceToHost, mb.stream), "copy max length");
-      HIP_TRY(hipStreamSynchronize(mb.stream), "hipStreamSynchronize");
-      maxPos = v;
-    }
+    if (positions && offsets && offsets[k])
+      maxPos = (mb.dfa->flags & REDGPU_F_FORCE_GENERIC) ? ~0ull : 0xffffffffull;
     pws[k] = widthFor(maxPos);
     recBytes[k] = planeBytes(n[k], rw) + (start ? planeBytes(n[k], pws[k]) : 0) +
                   (end ? planeBytes(n[k], pws[k]) : 0);
@@ -554,6 +543,10 @@ int redgpu_group_batch_dev(redgpu_group *g, int verb, int style, int do_leader,
     if (!n[k] && k != 0) continue;
     DeviceScope scope(g->m[k].device);
     HIP_TRY(hipEventRecord(g->m[k].done, g->m[k].stream), "hipEventRecord");
+    // ... and the shard's own stream may not touch (or free) its inputs before the scan has read them
+    if (shard_streams && n[k])
+      HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(shard_streams[k]), g->m[k].done, 0),
+              "hipStreamWaitEvent");
   }
   // 5. root: widen every shard's records into the caller's arrays, on the caller's stream
   {

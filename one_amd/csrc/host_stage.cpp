@@ -30,7 +30,7 @@ struct ScratchEntry {
   size_t bytes;
   uint64_t stamp;
 };
-constexpr size_t kMaxPerThread = 16;
+constexpr size_t kMaxPerThread = 48;
 std::atomic<size_t> gScratchCount{0};  // entries alive in all threads (redgpu_scratch_entries)
 
 void freeEntry(ScratchEntry &en) {
@@ -38,7 +38,12 @@ void freeEntry(ScratchEntry &en) {
   int cur = -1;
   const bool sw = hipGetDevice(&cur) == hipSuccess && cur != en.dev &&
                   hipSetDevice(en.dev) == hipSuccess;
-  (void)hipFree(en.ptr);  // waits for the work that may still be using it
+  // the buffer may still be read by kernels queued on its stream (which may itself be gone by
+  // now, so it cannot be asked): wait for the device, then free.  Only on the rare paths - a
+  // buffer outgrown, an entry evicted, a thread leaving.  (Round 2 relied on hipFree alone to
+  // wait; with evictions no longer rare a kernel faulted on its freed tail pad.)
+  (void)hipDeviceSynchronize();
+  (void)hipFree(en.ptr);
   if (sw) (void)hipSetDevice(cur);
   en.ptr = nullptr;
   en.bytes = 0;

@@ -30,18 +30,23 @@ struct ChunkBufs {
   uint64_t *end, *start;
 };
 
+// count[r] = chunks queued for re-walk in round r (one counter per round, all zeroed here: round 2
+// zeroed one shared counter with a memset in front of every round - six more launches per call)
 __global__ void __launch_bounds__(256)
 k_chunk_init(ChunkBufs cb, uint64_t nChunks, uint64_t n, uint32_t init) {
   const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
   if (i < nChunks) { cb.st[i] = init; cb.ent[i] = init; }
   if (i < n) cb.pos[i] = 0;
-  if (i == 0) *cb.count = 0;
+  if (i <= uint64_t(kChunkRounds)) cb.count[i] = 0;
 }
 
 // per line: advance over the chunks whose record is known to be right; stop at the first whose
-// entry state was guessed wrong and queue it
+// entry state was guessed wrong and queue it for this round.  A round behind one that queued
+// nothing has nothing to find (every line is through): it leaves at once.
 __global__ void __launch_bounds__(256)
-k_chunk_resolve(ChunkBufs cb, uint64_t n, uint32_t m, uint32_t init) {
+k_chunk_resolve(ChunkBufs cb, uint64_t n, uint32_t m, uint32_t init, int round) {
+  if (round > 0 && cb.count[round - 1] == 0) return;
+  cb.count += round;
   const uint64_t l = uint64_t(blockIdx.x) * 256 + threadIdx.x;
   if (l >= n) return;
   uint32_t j = cb.pos[l];
@@ -99,8 +104,9 @@ k_chunk_guess(DevDfa d, const uint8_t *data, uint32_t chunkLen, uint32_t m, uint
 
 template <int KIND, int kThreads>
 __global__ void __launch_bounds__(kThreads)
-k_chunk_rewalk(DevDfa d, const uint8_t *data, uint32_t chunkLen, ChunkBufs cb) {
+k_chunk_rewalk(DevDfa d, const uint8_t *data, uint32_t chunkLen, ChunkBufs cb, int round) {
   extern __shared__ __align__(16) uint8_t lds[];
+  cb.count += round;
   if (*cb.count == 0) return;  // uniform: nothing was guessed wrong this round
   uint8_t *eq = lds;
   uint8_t *leader = lds + 256;
@@ -206,11 +212,10 @@ hipError_t launchChunkTail(const DevDfa &d, const Batch &b, uint32_t m, uint32_t
   if (blocks == 0) blocks = 1;
   const uint32_t lineBlocks = uint32_t((b.n + 255) / 256);
   for (int round = 0; round < kChunkRounds; ++round) {
-    e = hipMemsetAsync(cb.count, 0, 4, stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_chunk_resolve, dim3(lineBlocks), dim3(256), 0, stream, cb, b.n, m, d.init);
+    hipLaunchKernelGGL(k_chunk_resolve, dim3(lineBlocks), dim3(256), 0, stream, cb, b.n, m, d.init,
+                       round);
     hipLaunchKernelGGL((k_chunk_rewalk<KIND, kThreads>), dim3(uint32_t(blocks)), dim3(kThreads),
-                       ldsBytes, stream, d, b.data, chunkLen, cb);
+                       ldsBytes, stream, d, b.data, chunkLen, cb, round);
   }
   // (no resolve here: one that queued a chunk without a re-walk behind it would leave that
   // chunk marked as done; k_chunk_combine continues from pos[] on its own)
@@ -238,7 +243,8 @@ inline hipError_t launchChunked(const DevDfa &d, const Batch &b, uint32_t m, int
   const uint64_t nChunks = uint64_t(m) * b.n;
   const uint32_t chunkLen = uint32_t(b.stride / m);
   // scratch: st, ent u32[nChunks]; acc i32[nChunks]; end, start u64[nChunks]; pos, work u32[n]; count
-  const size_t bytes = size_t(nChunks) * (4 + 4 + 4 + 8 + 8) + size_t(b.n) * 8 + 64 + 64;
+  const size_t bytes = size_t(nChunks) * (4 + 4 + 4 + 8 + 8) + size_t(b.n) * 8 + 64 + 64 +
+                       size_t(kChunkRounds) * 4;
   void *scratch = nullptr;
   hipError_t e = raggedScratch(stream, bytes, &scratch);
   if (e != hipSuccess) return e;

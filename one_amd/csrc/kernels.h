@@ -141,6 +141,12 @@ hipError_t launchDiagLines(const uint8_t *data, uint64_t nLines, uint32_t lineBy
                            uint64_t *st, uint64_t *en, uint32_t *sink, int numCUs,
                            hipStream_t stream);
 
+// bench.py's L2 gather calibration: `rounds` dependent 2-byte gathers per chain from a table of
+// 2^20 uint16 (2 MiB, device memory, any contents), 2 chains per lane, 2048 lanes per CU, no input
+// side; *lookups = gathers the launch performs.
+hipError_t launchDiagL2(const uint16_t *table, uint32_t rounds, uint32_t *sink, int numCUs,
+                        hipStream_t stream, uint64_t *lookups);
+
 // k_stream4.hip: the fixed-stride hot path with 3-4 chains per lane (mode = k_stream.h's
 // StreamMode value: Last+start+end 0, Last+end 1, Full+start 3, Full 4).
 bool stream4Eligible(const DevDfa &dfa, const Batch &b, const LaunchCfg &cfg);

@@ -856,6 +856,20 @@ int redgpu_diag_lds_dev(const redgpu_dfa *dfa, uint32_t rounds, uint32_t *sink, 
   return REDGPU_OK;
 }
 
+int redgpu_diag_l2_dev(const redgpu_dfa *dfa, const uint16_t *table, uint32_t rounds, uint32_t *sink,
+                       uint64_t *lookups, void *stream) {
+  if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
+  if (dfa->im->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (!table || !sink) return fail(REDGPU_EAPI, "null buffer");
+  DeviceScope scope(dfa->im->device);
+  if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  hipError_t e = launchDiagL2(table, rounds, sink, dfa->numCUs, static_cast<hipStream_t>(stream),
+                              lookups);
+  tlsKernel = "k_diag_l2";
+  if (e != hipSuccess) return failHip(e, "kernel launch");
+  return REDGPU_OK;
+}
+
 int redgpu_diag_walked_dev(const redgpu_dfa *dfa, int do_leader, const uint8_t *data,
                            const uint64_t *offsets, uint64_t stride, uint64_t n, uint64_t *walked,
                            void *stream) {

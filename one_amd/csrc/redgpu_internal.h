@@ -33,6 +33,10 @@ inline SharedImage::~SharedImage() {
   int prev = -1;
   const bool sw = hipGetDevice(&prev) == hipSuccess && prev != device &&
                   hipSetDevice(device) == hipSuccess;
+  // kernels queued with this image (asynchronous _dev calls the caller has not waited for) may
+  // still be reading its tables: drain the device before the tables go (the reference's rule is
+  // "exec must outlive the matcher", include/Matcher.h:772 - here breaking it is merely slow)
+  (void)hipDeviceSynchronize();
   if (dTable) (void)hipFree(dTable);
   if (dResult) (void)hipFree(dResult);
   if (dEquivLeader) (void)hipFree(dEquivLeader);

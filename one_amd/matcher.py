@@ -328,10 +328,14 @@ class Group:
         dp = (C.c_void_p * G)(*[d.data_ptr() for d in datas])
         op = (C.c_void_p * G)(*[o.data_ptr() for o in offs]) if ragged else None
         na = (C.c_uint64 * G)(*ns)
+        # every shard is ordered against torch's current stream of ITS device: the scan waits for
+        # what that stream has queued (the op that produced the shard) and the stream waits for the
+        # scan before it may reuse the shard's memory (torch's caching allocator is stream-ordered)
+        ss = (C.c_void_p * G)(*[torch.cuda.current_stream(d.device).cuda_stream for d in datas])
         _check(_lib.lib().redgpu_group_batch_dev(
             self._h, _VERBS[verb], int(style), 1 if do_leader else 0, dp, op, int(stride or 0), na,
             res.data_ptr(), st.data_ptr() if pos else None, en.data_ptr() if pos else None,
-            _lib.GATHER_RCCL if gather == "rccl" else _lib.GATHER_PEER,
+            _lib.GATHER_RCCL if gather == "rccl" else _lib.GATHER_PEER, ss,
             torch.cuda.current_stream(root).cuda_stream))
         return res, st, en
 

@@ -259,32 +259,3 @@ class StepGather:
         while self.inflight:
             self._finish_one()
         return self.last
-
-
-class FinalGather:
-    """bench.py helper: remembers the last step's outputs and gathers them once at the end
-    (the north-star's "RCCL over xGMI only for the final result gather")."""
-
-    def __init__(self, max_result: int, line_len: int, with_start: bool, via_host: bool = False,
-                 equal_counts: bool = False):
-        self.max_result, self.line_len, self.with_start = max_result, line_len, with_start
-        self.via_host = via_host  # gloo rehearsal: move the records through host memory
-        self.equal_counts = equal_counts
-        self.last = None
-        self.gathered = None
-
-    def push(self, outputs):
-        self.last = outputs
-
-    def flush(self):
-        if self.last is None:
-            return None
-        r, s, e = self.last
-        if self.via_host:
-            r, e = r.cpu(), e.cpu()
-            s = s.cpu() if s is not None else None
-        fin = gather_outcomes(r, s if self.with_start else None, e,
-                              max_result=self.max_result, max_line_len=self.line_len,
-                              equal_counts=self.equal_counts)
-        self.gathered = fin()
-        return self.gathered

@@ -1,5 +1,5 @@
 """Few long lines (configs[4] shape: 65,536 x 64 KiB): throughput is bounded by how many lines there
-are to spread over the CUs.  REDGPU_STREAM_THREADS=256|512|1024 picks the workgroup size."""
+are to spread over the CUs."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))

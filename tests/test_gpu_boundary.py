@@ -242,6 +242,60 @@ def test_group_device_shards_gathered_on_root(ndev, gather):
     assert _eq((r.cpu().numpy(), s.cpu().numpy(), e.cpu().numpy()), cat)
 
 
+def test_group_device_shards_are_stream_ordered():
+    """the shards' scans run on the group's private streams.  With shard_streams (the
+    Python wrapper passes torch's current stream of each device) the scan waits for the op that
+    PRODUCES the shard - queued, not finished, when batch_dev is called - and the producer stream
+    waits for the scan before the shard's memory may be reused: no synchronize anywhere between
+    producing, scanning and overwriting the shard."""
+    import torch
+    blob = load_dfa("uri")
+    cpu = O.CpuOracle(blob)
+    grp = one_amd.Group(blob, [0, 0])
+    stride, n = 4096, 6000
+    hosts = [W.fixed_lines(n, stride, 90 + g, alphabet=True, plant=W.URI_PLANT) for g in range(3)]
+    pinned = [torch.from_numpy(h).pin_memory() for h in hosts]
+    exp = [cpu.batch("match", 4, 0, h, stride=stride, n=n, threads=4) for h in hosts]
+    bufs = [torch.empty(n * stride, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    outs = []
+    for rep in range(6):
+        a, b = rep % 3, (rep + 1) % 3
+        bufs[0].copy_(pinned[a], non_blocking=True)   # queued on the current stream, not waited for
+        bufs[1].copy_(pinned[b], non_blocking=True)
+        r, s, e = grp.batch_dev("match", bufs, 4, 0, stride=stride)
+        outs.append((a, b, r.clone(), s.clone(), e.clone()))
+        bufs[0].zero_()                               # overwritten right behind the call
+        bufs[1].zero_()
+    torch.cuda.synchronize()
+    for a, b, r, s, e in outs:
+        cat = [np.concatenate([exp[a][k], exp[b][k]]) for k in range(3)]
+        assert _eq((r.cpu().numpy(), s.cpu().numpy(), e.cpu().numpy()), cat), (a, b)
+
+
+@pytest.mark.parametrize("gather", ["peer", "rccl"])
+def test_group_two_distinct_devices(gather):
+    """The multi-device data path of group.cpp - hipMemcpyPeerAsync / ncclSend + ncclRecv between
+    DISTINCT devices: runs wherever two GPUs are visible, skipped on a one-GPU box (where every
+    other group test names device 0 several times)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    blob = load_dfa("uri")
+    cpu = O.CpuOracle(blob)
+    grp = one_amd.Group(blob, [0, 1])
+    stride = 4096
+    counts = [5000, 5011]
+    hosts = [W.fixed_lines(c, stride, 70 + g, alphabet=True, plant=W.URI_PLANT)
+             for g, c in enumerate(counts)]
+    shards = [torch.from_numpy(h).to("cuda:%d" % g) for g, h in enumerate(hosts)]
+    for rep in range(3):
+        r, s, e = grp.batch_dev("match", shards, 4, 0, stride=stride, gather=gather)
+        torch.cuda.synchronize(0)
+        exp = [cpu.batch("match", 4, 0, h, stride=stride, n=c, threads=4) for h, c in zip(hosts, counts)]
+        cat = [np.concatenate([x[k] for x in exp]) for k in range(3)]
+        assert _eq((r.cpu().numpy(), s.cpu().numpy(), e.cpu().numpy()), cat), (gather, rep)
+
+
 @pytest.mark.parametrize("rw,pw,with_start", [(1, 1, True), (1, 2, True), (2, 4, False),
                                               (4, 8, True)])
 def test_record_planes_pack_and_unpack_roundtrip(rw, pw, with_start):

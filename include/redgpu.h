@@ -393,6 +393,16 @@ int redgpu_diag_walked_dev(const redgpu_dfa *dfa, int do_leader, const uint8_t *
 void redgpu_thread_release(void);
 uint64_t redgpu_scratch_entries(void);
 
+/* A caller that keeps its buffers from call to call (tools/thr_red.cpp's workers do) can pin them
+ * ONCE: the host-buffer entry points recognise pinned memory (registered here, or allocated by
+ * hipHostMalloc / torch's pin_memory) and then cut even a batch of a few MiB into 8 MiB chunks
+ * whose uploads, walks and downloads overlap on the thread's two streams - pageable memory is
+ * only pipelined above 64 MiB, where pinning it for the duration of one call pays.  The range
+ * must stay mapped until redgpu_host_unregister; (un)registering costs about a millisecond per
+ * 16 MiB, which is why the library does not do it per call on its own. */
+int redgpu_host_register(void *ptr, size_t bytes);
+int redgpu_host_unregister(void *ptr);
+
 /* ---- several GPUs of one node --------------------------------------------------------------
  * The reference scales by calling its read-only matcher from N threads over one shared Red
  * (tools/thr_red.cpp:84-91).  The device form of that picture: a GROUP holds one image of the

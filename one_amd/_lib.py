@@ -154,6 +154,10 @@ def lib() -> C.CDLL:
         l.redgpu_diag_l2_dev.argtypes = [vp, vp, C.c_uint32, vp, C.POINTER(u64), vp]
         l.redgpu_diag_walked_dev.restype = C.c_int
         l.redgpu_diag_walked_dev.argtypes = [vp, i32, vp, vp, u64, u64, vp, vp]
+        l.redgpu_host_register.restype = C.c_int
+        l.redgpu_host_register.argtypes = [vp, C.c_size_t]
+        l.redgpu_host_unregister.restype = C.c_int
+        l.redgpu_host_unregister.argtypes = [vp]
         l.redgpu_thread_release.restype = None
         l.redgpu_scratch_entries.restype = u64
         l.redgpu_group_create.restype = C.c_int

@@ -487,6 +487,23 @@ std::string buildImage(const void *reda, size_t len, uint32_t ldsTableMax, bool 
     }
   }
 
+  // is the leader the forced chain fixedPrefix would derive? (dfa_image.h: leaderForced)
+  if (img.leaderLen > 0 && img.deadAbsorbing) {
+    bool forced = true;
+    uint32_t s = img.init;
+    for (uint32_t i = 0; i < img.leaderLen && forced; ++i) {
+      if (s >= img.firstAccept || s < img.nPureDead) { forced = false; break; }
+      const uint32_t want = img.leader[i];
+      if (want >= nCls) { forced = false; break; }
+      for (uint32_t c = 0; c < nCls; ++c) {
+        const uint32_t t = img.next[size_t(s) * nCls + c];
+        if (c != want && t >= img.nPureDead) forced = false;
+      }
+      s = img.next[size_t(s) * nCls + want];
+    }
+    img.leaderForced = forced && s == img.leaderNext && s >= img.nPureDead;
+  }
+
   // L = SIGMA* L ?  (dfa_image.h: suffixClosed)  For every class c the language of the initial
   // state must be included in that of next(init, c): walk the product from (init, next(init, c)),
   // fail on a pair whose left accepts and whose right does not.  Pairs (x, x) hold trivially.

@@ -39,6 +39,14 @@ struct DfaImage {
   uint32_t firstAccept = 0;
   int32_t  maxResult = 0;
   bool     deadAbsorbing = true;  // every pure dead end self-loops on every class
+  // The leader is what DfaObj::fixedPrefix (lib/Dfa.cpp:146-168) derives from THIS table: walking
+  // its classes from the initial state reaches leaderNext, every state on the way is non-accepting
+  // and has no other way out than the leader's class (anything else falls into an absorbing pure
+  // dead end).  Then check<style,true> (include/Matcher.h:370-377: compare the leader, start in
+  // leaderOff_) is the plain walk from the initial state with ONE difference - the reference
+  // never looks at the result of the post-leader state itself unless the input ends there - and
+  // the streaming kernels can run it (k_stream.h: Batch::ignoreAcceptUpTo).
+  bool     leaderForced = false;
   // "Start bytes" for scan / search: the only input bytes at which an attempt can survive its
   // first step - with the leader, the bytes of the leader's first class; without, the bytes
   // whose transition out of the initial state is not a pure dead end.  Up to 4 are listed

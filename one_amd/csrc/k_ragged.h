@@ -780,12 +780,10 @@ hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
                          hipStream_t stream) {
   const uint64_t linesPerTile = uint64_t(kStreamThreads) * kStreamChains;
   const uint64_t tiles = (b.n + linesPerTile - 1) / linesPerTile;
-  // two workgroups per CU where the registers allow (the fused-table form: 119-122 VGPRs, 66 KB of
-  // LDS each): 16 waves hide the per-turn claims and the unaligned loads better than 8
-  // (REDGPU_RAGGED_WGS=1: the round-2 grid)
-  static const int wgs = [] { const char *e = getenv("REDGPU_RAGGED_WGS"); const int v = e ? atoi(e) : 2; return v == 1 ? 1 : 2; }();
-  const uint64_t want = uint64_t(cfg.numCUs) * uint64_t(TABK == kTabFused ? wgs : 1);
-  const uint64_t blocks = tiles < want ? tiles : want;
+  // one workgroup per CU.  (Two - the fused-table form fits, 119-122 VGPRs and 66 KB of LDS each -
+  // were measured in round 3: equal lines +6-8 % (2^23 x 256 B 2.70 -> 2.93 TB/s), mixed lengths
+  // -3 % (uniform 32-256: 1.60 -> 1.56), a 2^20-line batch of geometric lengths -18 %.)
+  const uint64_t blocks = tiles < uint64_t(cfg.numCUs) ? tiles : uint64_t(cfg.numCUs);
   Batch rb;
   LaunchCfg plain = cfg;
   plain.noBucketing = 1;  // lines are handed out in input order: nothing to sort

@@ -540,6 +540,9 @@ k_stream(DevDfa d, Batch io) {
           accS[c] = b[c].acc;
           endv[c] = b[c].end ? off + b[c].end : endv[c];
           if (s[c] >= firstAccept) { accS[c] = s[c]; endv[c] = off + 64; }
+          // check<..., true> over a forced leader: what accepted up to the end of the leader is
+          // not seen (Batch::ignoreAcceptUpTo; 0 otherwise, and an end is never 0)
+          if (endv[c] <= io.ignoreAcceptUpTo) { endv[c] = 0; accS[c] = 0; }
         }
         if (kAcc && IDXD) {
           if (b[c].end) { accS[c] = toGlobal(b[c].acc); endv[c] = off + b[c].end; }

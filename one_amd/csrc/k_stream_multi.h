@@ -30,7 +30,8 @@ struct MultiPtrs {
 struct MultiIo {
   uint32_t nb;       // batches, 1..kMultiMax
   uint32_t lineLen;  // bytes per line, a multiple of 64, the same for every batch
-  uint32_t tileStart[kMultiMax + 2];  // [k] = first tile of batch k; [nb] = tiles in all
+  uint32_t tileStart[kMultiMax + 1];  // [k] = first tile of batch k; [nb] = tiles in all
+  uint32_t ignoreAcceptUpTo;          // Batch::ignoreAcceptUpTo, the same for every batch
   MultiPtrs b[kMultiMax];
 };
 
@@ -313,6 +314,7 @@ k_stream_multi(DevDfa d, MultiIo m) {
           accS[c] = b[c].acc;
           endv[c] = b[c].end ? off + b[c].end : endv[c];
           if (s[c] >= firstAccept) { accS[c] = s[c]; endv[c] = off + 64; }
+          if (endv[c] <= m.ignoreAcceptUpTo) { endv[c] = 0; accS[c] = 0; }  // k_stream.h
         }
         if (kStart) {
           startv[c] = b[c].start ? off + b[c].start - 1 : startv[c];
@@ -413,7 +415,7 @@ hipError_t launchStreamLean4(const DevDfa &d, const MultiIo &m, const LaunchCfg 
   const uint64_t lpt = uint64_t(kStreamThreads) * kStreamChains * 2;
   for (uint32_t k = 0; k < m.nb; ++k)
     m4.tileStart[k + 1] = m4.tileStart[k] + uint32_t((m.b[k].n + lpt - 1) / lpt);
-  for (uint32_t k = m.nb; k < uint32_t(kMultiMax) + 1; ++k) m4.tileStart[k + 1] = m4.tileStart[m.nb];
+  for (uint32_t k = m.nb; k < uint32_t(kMultiMax); ++k) m4.tileStart[k + 1] = m4.tileStart[m.nb];
   const uint32_t tiles = m4.tileStart[m4.nb];
   const uint32_t blocks = tiles < uint32_t(cfg.numCUs) ? tiles : uint32_t(cfg.numCUs);
   hipLaunchKernelGGL((k_stream_multi<MODE, 1, kStreamThreads, 2, true, 2>), dim3(blocks),

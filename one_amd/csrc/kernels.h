@@ -39,6 +39,7 @@ struct DevDfa {
   uint32_t suffixClosed;         // L = SIGMA* L (dfa_image.h): a failed attempt that reached the end
                                  // of the line ends scan / search / collect
   uint32_t gatherNt;             // REDGPU_GATHER_NT=1: non-temporal table gathers (tuning experiment)
+  uint32_t leaderForced;         // the leader is the table's own forced prefix chain (dfa_image.h)
   // start bytes for scan / search (dfa_image.h): packed members, count (0xff = no filter)
   uint32_t startLeadWord, startLeadCount, startFreeWord, startFreeCount;
   uint32_t start2LeadWord, start2LeadCount, start2FreeWord, start2FreeCount;
@@ -61,6 +62,9 @@ struct Batch {
   const uint32_t *perm = nullptr; // k_ragged only: slot -> line (lines bucketed by length)
   const uint8_t *pad = nullptr;   // k_ragged only: copy of the buffer's last 128 bytes + zeros
   uint32_t spread = 1;            // k_generic only: one line per `spread` lanes (table in L2)
+  uint32_t ignoreAcceptUpTo = 0;  // k_stream / k_stream_multi, check<..., true> over a forced leader:
+                                  // accepts at positions <= this (the post-leader state's own
+                                  // result, include/Matcher.h:370-381) are not seen
 };
 
 struct LaunchCfg {

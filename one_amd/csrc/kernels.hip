@@ -158,8 +158,16 @@ hipError_t launchFixedFamily(const DevDfa &d, const Batch &b, int verb, int styl
                        b.stride % 16 == 0 && b.stride < (1ull << 31) &&
                        (reinterpret_cast<uintptr_t>(b.data) % 16) == 0 &&
                        !(lead && verb == kCheck);
+  // ... and check<styLast / styFull, true> when the leader is the table's own forced chain
+  // (dfa_image.h: leaderForced): the plain walk from the initial state, deaf to whatever accepts
+  // up to the leader's end (a line that IS the leader would report the post-leader state's
+  // result: left to k_generic)
+  const bool leadCheckOk = lead && verb == kCheck && d.leaderForced && b.stride > d.leaderLen &&
+                           (style == kStyLast || style == kStyFull) && !cfg.forceGeneric && !dying &&
+                           fastPathEligible(d) && !b.offsets && b.stride % 64 == 0 &&
+                           b.stride < (1ull << 31) && (reinterpret_cast<uintptr_t>(b.data) % 16) == 0;
   // Streaming kernel: styles Last / Full on lines that are whole 64-byte blocks.
-  const bool streamOk = fixedOk && (style == kStyLast || style == kStyFull) &&
+  const bool streamOk = (fixedOk || leadCheckOk) && (style == kStyLast || style == kStyFull) &&
                         b.stride % 64 == 0 && d.tableBytes <= kStreamTabBytes && d.nStates <= 256;
   // The same streaming walk for DFAs too big for LDS: hot rows as a one-byte-indexed table,
   // cold excursions re-walked per 64-byte half-block (k_stream.h, HOT).
@@ -178,7 +186,8 @@ hipError_t launchFixedFamily(const DevDfa &d, const Batch &b, int verb, int styl
                            !(lead && verb == kCheck);
   // Few long lines over a DFA that forgets its past: chunks of every line walked at once from
   // the initial state as a guess, wrong guesses re-walked (k_chunk.h)
-  if ((streamOk || hotStreamOk || clsStreamOk) && !cfg.noChunking &&
+  const bool leadCheck = lead && verb == kCheck;  // (only ever true here with leadCheckOk)
+  if ((streamOk || hotStreamOk || clsStreamOk) && !cfg.noChunking && !leadCheck &&
       (d.forgetful || cfg.forceChunking) &&
       (fewLines(b, cfg) || cfg.forceChunking)) {
     const uint32_t m = chunksPerLine(b, cfg);
@@ -202,6 +211,7 @@ hipError_t launchFixedFamily(const DevDfa &d, const Batch &b, int verb, int styl
     hipError_t e;
     Batch sb = b;
     if (verb == kCheck) { sb.start = nullptr; sb.end = nullptr; }
+    if (leadCheck) sb.ignoreAcceptUpTo = d.leaderLen;
     static const int labLean = multiLabInt("REDGPU_LEAN", 0, 1, 0);
     static const int labSingle = multiLabInt("REDGPU_MULTI_SINGLE", 0, 1, 0);
     if (cfg.forceLean || labLean || labSingle) {
@@ -210,7 +220,7 @@ hipError_t launchFixedFamily(const DevDfa &d, const Batch &b, int verb, int styl
       e = launchStreamBatches(d, &b, 1, verb, style, doLeader, cfg, stream, kernelName, &taken);
       if (e != hipSuccess || taken) return e;
     }
-    if (stream4Eligible(d, sb, cfg)) {
+    if (!leadCheck && stream4Eligible(d, sb, cfg)) {
       const int mode = style == kStyLast ? (sb.start ? kSmLastStartEnd : kSmLastEnd)
                                          : (sb.start ? kSmFullStart : kSmFull);
       *kernelName = style == kStyLast ? (sb.start ? "k_stream4<last,start,end>" : "k_stream4<last,end>")
@@ -225,7 +235,7 @@ hipError_t launchFixedFamily(const DevDfa &d, const Batch &b, int verb, int styl
       else { *kernelName = "k_stream<full>"; e = launchStreamT<kSmFull>(d, sb, cfg, stream); }
     }
     if (e != hipSuccess) return e;
-    if (lead) {
+    if (lead && !leadCheck) {
       hipLaunchKernelGGL(k_leader_filter, dim3(uint32_t(cfg.numCUs) * 8), dim3(256), 0, stream,
                          d, b);
       return hipGetLastError();
@@ -321,6 +331,7 @@ hipError_t launchStreamBatches(const DevDfa &d, const Batch *bs, uint32_t nb, in
   MultiIo m;
   m.nb = 0;
   m.lineLen = uint32_t(bs[0].stride);
+  m.ignoreAcceptUpTo = 0;
   m.tileStart[0] = 0;
   const uint64_t lpt = uint64_t(kStreamThreads) * kStreamChains;
   for (uint32_t k = 0; k < nb && m.nb < uint32_t(kMultiMax); ++k) {
@@ -342,7 +353,7 @@ hipError_t launchStreamBatches(const DevDfa &d, const Batch *bs, uint32_t nb, in
   if (m.nb < ((labSingle || lean) ? 1u : 2u) ||
       (m.tileStart[m.nb] < uint32_t(cfg.numCUs) && !(lean && cfg.forceLean)))
     return hipSuccess;
-  for (uint32_t k = m.nb; k < uint32_t(kMultiMax) + 1; ++k) m.tileStart[k + 1] = m.tileStart[m.nb];
+  for (uint32_t k = m.nb; k < uint32_t(kMultiMax); ++k) m.tileStart[k + 1] = m.tileStart[m.nb];
   hipError_t e;
   if (style == kStyLast) {
     if (wantStart) { *kernelName = lean ? "k_stream_multi<last,start,end,lean>" : "k_stream_multi<last,start,end>"; e = launchStreamMultiT<kSmLastStartEnd>(d, m, cfg, stream); }

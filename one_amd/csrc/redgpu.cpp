@@ -157,6 +157,17 @@ static uint64_t hostChunkBytes() {
 }
 #define kHostChunkBytes hostChunkBytes()
 
+// is p host memory the runtime knows as pinned (hipHostMalloc / hipHostRegister)?
+static bool isPinnedHost(const void *p) {
+  if (!p) return false;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // plain pageable memory: not an error of the call
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
 // offsets of a chunk that does not start at byte 0, rebased to the chunk's own buffer: the
 // kernels may read data[0, offsets[n]) anywhere (lanes without a line re-read block 0), so a
 // chunk is always presented as a batch of its own
@@ -194,19 +205,28 @@ int runHost(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint
   HostStage *st = nullptr;
   if (int rc = stageOf(dfa, &st)) return rc;
 
+  // Caller memory that is already pinned (redgpu_host_register, hipHostMalloc, torch's
+  // pin_memory): its copies are asynchronous as they stand, so even a batch of a few MiB is worth
+  // cutting - chunks of 8 MiB alternate between the two streams and the upload of one runs beside
+  // the walk and the download of the one before.  Pageable memory keeps the 32 MiB chunks and is
+  // only cut (and pinned for the call) above 64 MiB: below that the pinning costs more than the
+  // overlap returns.
+  const bool callerPinned = isPinnedHost(data) && isPinnedHost(result) &&
+                            (!start || isPinnedHost(start)) && (!end || isPinnedHost(end));
+  const uint64_t chunkBytes = callerPinned ? (8ull << 20) : kHostChunkBytes;
   // chunk plan: cuts[c] .. cuts[c + 1] are the lines of chunk c
   std::vector<uint64_t> cuts{0};
   const uint64_t base0 = offsets ? offsets[0] : 0;
-  if (total - base0 > 2 * kHostChunkBytes && n >= 4096) {
+  if (total - base0 > 2 * chunkBytes && n >= 4096) {
     if (!offsets) {
-      uint64_t per = (kHostChunkBytes / (stride ? stride : 1)) & ~uint64_t(1023);
+      uint64_t per = (chunkBytes / (stride ? stride : 1)) & ~uint64_t(1023);
       if (per < 1024) per = 1024;
       for (uint64_t lo = per; lo < n; lo += per) cuts.push_back(lo);
     } else {
       uint64_t lo = 0;
       while (lo < n) {
-        // first line whose start is >= kHostChunkBytes past this chunk's start
-        const uint64_t target = offsets[lo] + kHostChunkBytes;
+        // first line whose start is >= chunkBytes past this chunk's start
+        const uint64_t target = offsets[lo] + chunkBytes;
         uint64_t a = lo + 1, b = n;
         while (a < b) {
           const uint64_t mid = (a + b) / 2;
@@ -250,8 +270,9 @@ int runHost(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint
 
   // pinned caller memory makes the copies truly asynchronous (only worth its price when there
   // is something to overlap)
-  ScopedPin pinIn(data, total, multi), pinRes(result, n * 4, multi),
-      pinStart(start, start ? n * 8 : 0, multi), pinEnd(end, end ? n * 8 : 0, multi);
+  const bool pinNow = multi && !callerPinned;
+  ScopedPin pinIn(data, total, pinNow), pinRes(result, n * 4, pinNow),
+      pinStart(start, start ? n * 8 : 0, pinNow), pinEnd(end, end ? n * 8 : 0, pinNow);
 
   if (offsets) {
     STAGE_TRY(hipMemcpyAsync(dOff, offsets, (n + 1) * 8, hipMemcpyHostToDevice, st->streams[0]),
@@ -371,6 +392,7 @@ int uploadImage(SharedImage *im) {
   d.forgetful = img.forgetful ? 1 : 0;
   d.suffixClosed = img.suffixClosed ? 1 : 0;
   d.uniformResult = img.uniformResult ? 1 : 0;
+  d.leaderForced = img.leaderForced ? 1 : 0;
   {
     const char *e = getenv("REDGPU_GATHER_NT");
     d.gatherNt = e && e[0] == '1';
@@ -889,6 +911,20 @@ int redgpu_diag_walked_dev(const redgpu_dfa *dfa, int do_leader, const uint8_t *
                               static_cast<hipStream_t>(stream));
   tlsKernel = "k_walked";
   if (e != hipSuccess) return failHip(e, "kernel launch");
+  return REDGPU_OK;
+}
+
+int redgpu_host_register(void *ptr, size_t bytes) {
+  if (!ptr || !bytes) return fail(REDGPU_EAPI, "null buffer");
+  hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) return failHip(e, "hipHostRegister");
+  return REDGPU_OK;
+}
+
+int redgpu_host_unregister(void *ptr) {
+  if (!ptr) return fail(REDGPU_EAPI, "null buffer");
+  hipError_t e = hipHostUnregister(ptr);
+  if (e != hipSuccess) return failHip(e, "hipHostUnregister");
   return REDGPU_OK;
 }
 

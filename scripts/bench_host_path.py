@@ -34,3 +34,44 @@ for n, L in ((1 << 20, 64), (1 << 18, 1024), (1 << 18, 4096)):
     dt = (time.perf_counter() - t0) / k
     print("%8d x %5d B host buffers, %d threads: %8.2f ms/batch %6.1f GB/s of input" %
           (n, L, T, dt * 1e3, n * L / dt / 1e9), flush=True)
+
+# ---- the same through the C-ABI with caller buffers kept from call to call, pageable and pinned
+# (redgpu_host_register): what a C++ caller that reuses its vectors gets
+from one_amd import _lib
+l = _lib.lib()
+for n, L in ((1 << 20, 64), (1 << 18, 1024)):
+    for pinned in (False, True):
+        T = 4
+        sets = []
+        for i in range(T + 1):
+            m = n if i == 0 else n // T
+            d = W.fixed_lines(m, L, 1 + i, alphabet=False)
+            r = np.zeros(m, dtype=np.int32); s = np.zeros(m, dtype=np.uint64); e = np.zeros(m, dtype=np.uint64)
+            if pinned:
+                for a in (d, r, s, e):
+                    assert l.redgpu_host_register(a.ctypes.data, a.nbytes) == 0
+            sets.append((d, r, s, e, m))
+        def call(i):
+            d, r, s, e, m = sets[i]
+            rc = l.redgpu_match_batch(exe._h, 4, 0, d.ctypes.data, None, L, m, r.ctypes.data, s.ctypes.data, e.ctypes.data)
+            assert rc == 0, l.redgpu_last_error()
+        for _ in range(2): call(0)
+        k = 8
+        t0 = time.perf_counter()
+        for _ in range(k): call(0)
+        dt = (time.perf_counter() - t0) / k
+        one = n * L / dt / 1e9
+        for i in range(1, T + 1): call(i)
+        def work(i):
+            for _ in range(k): call(i)
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(1, T + 1)]
+        t0 = time.perf_counter()
+        for t in ths: t.start()
+        for t in ths: t.join()
+        dt4 = (time.perf_counter() - t0) / k
+        print("%8d x %5d B C-ABI, caller buffers %-8s: 1 thread %6.2f ms/call %6.1f GB/s | 4 threads (a quarter each) %6.2f ms %6.1f GB/s" %
+              (n, L, "PINNED" if pinned else "pageable", dt * 1e3, one, dt4 * 1e3, n * L / dt4 / 1e9), flush=True)
+        if pinned:
+            for d, r, s, e, m in sets:
+                for a in (d, r, s, e):
+                    l.redgpu_host_unregister(a.ctypes.data)

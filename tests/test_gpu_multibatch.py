@@ -201,3 +201,38 @@ def test_lean_step_long_lines_vs_oracle(name, stride, n, chains):
     exp = cpu.batch("match", 4, 0, h, stride=stride, n=n, threads=8)
     _same(outs[0], exp, "two batches, first")
     _same(outs[1], exp, "two batches, second")
+
+
+@pytest.mark.parametrize("stride,n", [(64, 70000), (128, 9000), (4096, 2100), (192, 5000)])
+@pytest.mark.parametrize("name", ["err", "newyork", "aab"])
+def test_check_with_leader_on_the_streaming_kernel(name, stride, n):
+    """check<styLast / styFull, true> (include/Matcher.h:370-381: compare the leader, start in the
+    post-leader state) over a DFA whose leader is its table's own forced prefix chain runs on
+    k_stream - the plain walk, deaf to whatever accepts up to the leader's end.  The quirk that
+    makes this more than check<..., false>: the post-leader state's own result is never looked at
+    unless the line ends there - ERR ('error', leader = the whole pattern) reports 0 for
+    'error foo'.  Lines that start with the pattern, hold it later, or hold a broken prefix."""
+    import torch
+    blob = load_dfa(name)
+    exe = one_amd.Executable(blob, force_stream=True, no_chunking=True)
+    cpu = O.CpuOracle(blob)
+    plant = {"err": b"error", "newyork": b"New York", "aab": b"aab"}[name]
+    h = W.fixed_lines(n, stride, 5 * stride + n, plant=plant, plant_every=3, plant_at=20)
+    v = h.reshape(n, stride)
+    v[1::4, :len(plant)] = np.frombuffer(plant, dtype=np.uint8)              # the pattern at the start
+    v[2::9, :len(plant) - 1] = np.frombuffer(plant[:-1], dtype=np.uint8)     # all of it but its last byte
+    v[5::13, :len(plant)] = np.frombuffer(plant, dtype=np.uint8)
+    v[5::13, len(plant):2 * len(plant)] = np.frombuffer(plant, dtype=np.uint8)  # twice in a row
+    d = torch.from_numpy(h).cuda()
+    for si in (4, 5):
+        cr = cpu.batch("check", si, 1, h, stride=stride, n=n, threads=4)[0]
+        r = one_amd.check_batch(exe, d, si, 1, stride=stride, n=n)
+        k = one_amd.last_kernel()
+        torch.cuda.synchronize()
+        assert k.startswith("k_stream<"), k
+        assert np.array_equal(r.cpu().numpy(), cr), (name, stride, si, k)
+    # the quirk is in the data: with and without the leader differ somewhere for ERR
+    if name == "err":
+        a = cpu.batch("check", 4, 1, h, stride=stride, n=n, threads=4)[0]
+        b = cpu.batch("check", 4, 0, h, stride=stride, n=n, threads=4)[0]
+        assert not np.array_equal(a, b)

@@ -168,9 +168,11 @@ class Workload:
             self.offsets_dev = torch.from_numpy(offsets.astype("int64")).cuda()
             self.in_bytes = int(offsets[-1])
         nout = max(3, 2 * (a.streams or 1), a.per_call or 1)
-        self.outs = [(torch.empty(n, dtype=torch.int32, device="cuda"),
-                      torch.empty(n, dtype=torch.int64, device="cuda") if self.want_start else None,
-                      torch.empty(n, dtype=torch.int64, device="cuda")) for _ in range(nout)]
+        # (zeroed, not just reserved: every page of every output set has been written once before
+        # any clock starts, whichever sets the W warm-up steps happen to use)
+        self.outs = [(torch.zeros(n, dtype=torch.int32, device="cuda"),
+                      torch.zeros(n, dtype=torch.int64, device="cuda") if self.want_start else None,
+                      torch.zeros(n, dtype=torch.int64, device="cuda")) for _ in range(nout)]
         self.out_bytes = n * (4 + 8 + (8 if self.want_start else 0)) + (8 * n if self.ragged else 0)
 
     # -- one step --------------------------------------------------------------------------
@@ -510,8 +512,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
 
+    ev0.record()           # (asynchronous: the idle GPU stamps it at once; its host cost is not a step's)
     t0 = time.perf_counter()
-    ev0.record()
     run_steps(args.steps)
     if streams is not None:
         for st in streams:

@@ -68,3 +68,27 @@ for total, p_nl in ((1 << 26, 1 / 64), (1 << 28, 1 / 144)):
     ms = timed(lambda: one_amd.match_batch(exe, dev, 4, False, offsets=o, stride=1, out=(res, st, en)), 20)
     print("match     same lines (delimiter dropped)      %8.1f us  %7.1f GB/s  %s" % (ms * 1e3, total / ms / 1e6, one_amd.last_kernel()), flush=True)
     del dev
+
+# replace<styLast,false> on device-resident lines (redgpu_replace_batch_dev): count pass, prefix sum
+# of the rewritten lengths, write pass - sizes only (out = NULL) and with the rewritten bytes
+import ctypes as C
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
+from golden_util import load_dfa as _ld
+uexe = one_amd.Executable(_ld("uri"))
+for n, L in ((1 << 20, 64), (1 << 18, 1024)):
+    host = W.fixed_lines(n, L, 5, plant=W.URI_PLANT, plant_every=4, plant_at=8)
+    dev = torch.from_numpy(host).cuda()
+    repl = torch.from_numpy(np.frombuffer(b"<url>", dtype=np.uint8).copy()).cuda()
+    counts = torch.empty(n, dtype=torch.int64, device="cuda")
+    ooff = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    out = torch.empty(n * L + 64, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for label, optr in (("sizes only", None), ("with bytes", out.data_ptr())):
+        fn = lambda: l.redgpu_replace_batch_dev(uexe._h, 4, 0, dev.data_ptr(), None, L, n, repl.data_ptr(), 5,
+                                                1 << 62, counts.data_ptr(), ooff.data_ptr(), optr, out.numel(), stream)
+        assert fn() == 0, l.redgpu_last_error()
+        ms = timed(fn, 10)
+        print("replace   %8d x %5d B  URI-D, url in every 4th line, %-10s  %8.1f us  %7.1f GB/s  (%d replacements)" %
+              (n, L, label, ms * 1e3, n * L / ms / 1e6, int(counts.sum().item())), flush=True)
+    del dev

@@ -21,6 +21,7 @@ run prof_ragged.py uri_v6
 run prof_ragged.py uri_v6 generic
 run bench_log100.py
 run bench_matchall_cap.py
+run bench_host_path.py
 run bench_strides.py syn256
 run bench_ragged_styles.py
 echo secondary_done

@@ -434,6 +434,7 @@ def main():
         last_call[:] = [((i + k) % len(wl.bufs), (i + k) % len(wl.outs)) for k in range(cnt)]
 
     plans = {}
+    host_trace = []
 
     def plan_of(count):
         """the multi-batch calls of `count` steps: (descriptor window, steps in it), built once"""
@@ -446,9 +447,11 @@ def main():
         """`count` steps, the way this run issues them; returns the last step's outputs"""
         if per_call > 1:
             h, sty, lead = wl.exe._h, wl.style, wl.lead
+            ta = time.perf_counter()
             for win, cnt, i in plan_of(count):
                 if fn_many(h, sty, lead, win, cnt, cur_stream) != 0:
                     raise RuntimeError(_lib.lib().redgpu_last_error().decode())
+            host_trace[:] = [ta, time.perf_counter()]
             if count:
                 last_call[:] = [((i + k) % len(wl.bufs), (i + k) % len(wl.outs)) for k in range(cnt)]
             return wl.outs[(count - 1) % len(wl.outs)]
@@ -859,6 +862,8 @@ def main():
                          "the ~1.5 us dependent-launch gap)" % (launches_timed, kernel_name),
         "timed_region_ms_per_step": round(region_ms / args.steps, 5),
         "timed_region_host_issue_ms": round((t_issued - t0) * 1e3, 5),
+        "timed_region_library_calls_ms": (round((host_trace[1] - host_trace[0]) * 1e3, 5)
+                                          if len(host_trace) == 2 else None),
     }
     if batches_per_launch > 1:
         # the same workload one batch per launch (redgpu_match_batch_dev per step): what a caller

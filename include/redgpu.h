@@ -343,6 +343,30 @@ int redgpu_split_lines(const redgpu_dfa *dfa, const uint8_t *data, uint64_t len,
 int redgpu_split_lines_dev(const redgpu_dfa *dfa, const uint8_t *data, uint64_t len, uint8_t delim,
                            uint64_t *offsets, uint64_t cap, uint64_t *n_lines, void *stream);
 
+/* Raw text in, one Outcome per line out, in ONE call: the loop of tools/skim_red.cpp:36-46 over
+ * the lines lib/Util.cpp:109-130 cuts (find the delimiter, hand [start, delimiter) to the
+ * matcher, go on behind it).  Equal to redgpu_split_lines[_dev] followed by
+ * redgpu_check/match_batch[_dev] over (offsets, stride = 1) - same offsets[] (cap + 1 entries, the
+ * caller's: positions are relative to a line's start, so the caller needs them to place a match
+ * in the buffer), same *n_lines (delimiters found, may exceed cap), result/start/end filled for
+ * the first min(*n_lines, cap) lines - but the line count never visits the host in between:
+ * for the DFAs the ragged streaming kernels take (styles Last / Full, no leader to honour, table
+ * in LDS or hot rows - redgpu_last_kernel says "k_ragged...") the walk reads it on the device and
+ * the _dev call is asynchronous on `stream` from end to end; for the others the call waits for
+ * the split once (8 bytes back) and launches what redgpu_*_batch_dev would.
+ * _dev: all pointers device memory.  redgpu_match_text: host buffers; start / end may be NULL
+ * (both NULL = check). */
+int redgpu_check_text_dev(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                          uint64_t len, uint8_t delim, uint64_t *offsets, uint64_t cap,
+                          uint64_t *n_lines, int32_t *result, void *stream);
+int redgpu_match_text_dev(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                          uint64_t len, uint8_t delim, uint64_t *offsets, uint64_t cap,
+                          uint64_t *n_lines, int32_t *result, uint64_t *start, uint64_t *end,
+                          void *stream);
+int redgpu_match_text(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                      uint64_t len, uint8_t delim, uint64_t *offsets, uint64_t cap,
+                      uint64_t *n_lines, int32_t *result, uint64_t *start, uint64_t *end);
+
 /* Measurement aid, no counterpart in the reference: one streaming read of `bytes` of device
  * memory (16-byte aligned) on the handle's device, asynchronous on `stream` - the read-bandwidth
  * calibration bench.py reports beside the roofline.  `sink` is a device uint32 the kernel may

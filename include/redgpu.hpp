@@ -165,6 +165,26 @@ inline std::vector<Outcome> matchBatch(const Executable &exec, const std::vector
   return out;
 }
 
+// The lines of a text blob (lib/Util.cpp:109-130's rule: [start, delimiter), bytes behind the last
+// delimiter are not a line), each matched - the loop of tools/skim_red.cpp:36-46 in one call.
+// lineStarts (optional) receives where each line begins in `text`; Outcome positions are relative
+// to that, as if the line had been handed to match() on its own.
+inline std::vector<Outcome> matchText(const Executable &exec, std::string_view text, Style style,
+                                      bool doLeader = true, char delim = '\n',
+                                      std::vector<size_t> *lineStarts = nullptr) {
+  const Byte *p = reinterpret_cast<const Byte *>(text.data());
+  uint64_t n = 0, none = 0;
+  throwOnError(redgpu_split_lines(exec.handle(), p, text.size(), Byte(delim), &none, 0, &n));
+  std::vector<uint64_t> off(n + 1, 0), s(n), e(n);
+  std::vector<Result> r(n);
+  throwOnError(redgpu_match_text(exec.handle(), style, doLeader, p, text.size(), Byte(delim),
+                                 off.data(), n, &n, r.data(), s.data(), e.data()));
+  std::vector<Outcome> out(r.size());
+  for (size_t i = 0; i < out.size(); ++i) out[i] = Outcome{r[i], size_t(s[i]), size_t(e[i])};
+  if (lineStarts) lineStarts->assign(off.begin(), off.begin() + out.size());
+  return out;
+}
+
 // ---- several GPUs of one node: one image per device, contiguous shards, results in the caller's
 // arrays - the device form of tools/thr_red.cpp:84-91 (N workers over one shared Red).  devices
 // may name a device more than once (the shards then share it). ----------------------------------

@@ -10,11 +10,11 @@ from .matcher import (Executable, Group, Style, RedExcept, RedExceptApi, RedExce
                       RedExceptLimit, RedExceptHip, check, check_batch, check_header, match,
                       match_batch, match_batches, check_batches, batch_descs, scan, scan_batch, search, search_batch, collect,
                       collect_batch, match_all, match_all_batch, advance_batch,
-                      StatefulMatcher, STATE_INITIAL, split_lines, replace, replace_batch, last_kernel, styInstant, styFirst,
+                      StatefulMatcher, STATE_INITIAL, split_lines, match_text, replace, replace_batch, last_kernel, styInstant, styFirst,
                       styTangent, styLast, styFull)
 
 __all__ = ["Executable", "Group", "Style", "check", "match", "scan", "check_batch", "match_batch",
            "scan_batch", "search", "search_batch", "collect", "collect_batch", "check_header",
            "match_all", "match_all_batch", "advance_batch", "StatefulMatcher", "STATE_INITIAL",
-           "split_lines", "replace", "replace_batch", "last_kernel", "match_batches",
+           "split_lines", "match_text", "replace", "replace_batch", "last_kernel", "match_batches",
            "check_batches", "batch_descs"]

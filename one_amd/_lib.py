@@ -144,6 +144,15 @@ def lib() -> C.CDLL:
         l.redgpu_split_lines.argtypes = [vp, vp, u64, C.c_uint8, vp, u64, vp]
         l.redgpu_split_lines_dev.restype = C.c_int
         l.redgpu_split_lines_dev.argtypes = [vp, vp, u64, C.c_uint8, vp, u64, vp, vp]
+        l.redgpu_check_text_dev.restype = C.c_int
+        l.redgpu_check_text_dev.argtypes = [vp, C.c_int, C.c_int, vp, u64, C.c_uint8, vp, u64, vp,
+                                            vp, vp]
+        l.redgpu_match_text_dev.restype = C.c_int
+        l.redgpu_match_text_dev.argtypes = [vp, C.c_int, C.c_int, vp, u64, C.c_uint8, vp, u64, vp,
+                                            vp, vp, vp, vp]
+        l.redgpu_match_text.restype = C.c_int
+        l.redgpu_match_text.argtypes = [vp, C.c_int, C.c_int, vp, u64, C.c_uint8, vp, u64, vp,
+                                        vp, vp, vp]
         l.redgpu_diag_read_dev.restype = C.c_int
         l.redgpu_diag_read_dev.argtypes = [vp, vp, u64, vp, vp]
         l.redgpu_diag_lds_dev.restype = C.c_int

@@ -194,6 +194,13 @@ __device__ __forceinline__ void raggedWalk16Cls(const uint4 (&piece)[2], uint32_
 #undef RGC_WORD
 }
 
+// lines of the batch: Batch::n, or what the device-side count says if that is fewer
+__device__ __forceinline__ uint64_t raggedLineCount(uint64_t n, const uint64_t *nDev) {
+  if (!nDev) return n;
+  const uint64_t have = *nDev;
+  return have < n ? have : n;
+}
+
 // a wave-uniform 64-bit value the compiler must keep in SGPRs (it feeds "s" asm operands)
 __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
   const uint32_t lo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v))));
@@ -253,7 +260,14 @@ __device__ __noinline__ SlowBook slowRagged(const DevDfa &d, const uint8_t *tab8
 //    that is claimed, and its offsets requested, at the top of the block in which the current
 //    line ends - a whole block's walk ahead of the first use, unconditionally (lanes that claim
 //    nothing re-read offsets[0..1]) so the compiler's vmcnt counts stay exact;
-//  * an empty line takes one block slot with no valid step.
+//  * an empty line takes one block slot with no valid step;
+//  * a launch cannot end before the line that was started last has been walked by its one lane,
+//    a 64-byte block per turn: on skewed lengths (geometric text: the longest of 2^21 lines is
+//    14 x the mean) that tail was longer than everything before it.  k_ragged_outliers lists the
+//    lines of at least `outCtl[1]` bytes (a multiple of the batch's mean length, so they are few);
+//    every workgroup takes its share of that list FIRST - slots [0, nOutW) of its cursor - and
+//    then its contiguous range, in which those lines are passed over.  The long lines so run
+//    beside the bulk instead of after it, and the tail is at most the threshold long.
 // =========================================================================================
 template <int MODE, int TABK = kTabFused>
 __global__ void __launch_bounds__(kStreamThreads)
@@ -320,7 +334,8 @@ k_ragged(DevDfa d, Batch io) {
   asm volatile("" : : "v"(tab) : "memory");  // the table is read from inline asm: see k_stream.h
   __syncthreads();
 
-  const uint64_t total = io.offsets[io.n];
+  const uint64_t nLines = raggedLineCount(io.n, io.nDev);
+  const uint64_t total = io.offsets[nLines];
   const uint64_t padStart = total >= 128 ? total - 128 : 0;  // pad[] = data[padStart, total) + 0s
   const int32_t initResult = IDXD ? (d.init >= d.firstAccept ? d.result[d.init] : 0)
                                  : (init >= firstAccept ? ldsRes[init] : 0);
@@ -329,9 +344,15 @@ k_ragged(DevDfa d, Batch io) {
   // measured slower at every shape, 591 against 706 GB/s on geometric lengths: the sort costs
   // 13 us, the lanes of a wave then read all over the buffer, and the permutation entry is a
   // dependent load in front of the offsets.  DESIGN.md section 7 has what to try instead.)
-  const uint64_t lo = io.n * blockIdx.x / gridDim.x;
-  const uint32_t range = uint32_t(io.n * (blockIdx.x + 1) / gridDim.x - lo);
+  const uint64_t lo = nLines * blockIdx.x / gridDim.x;
+  const uint32_t range = uint32_t(nLines * (blockIdx.x + 1) / gridDim.x - lo);
   const uint32_t lane = threadIdx.x & 63u;
+  // the long lines: this workgroup's share of the list, and the length that makes a line one
+  const uint32_t nOut = io.outCtl ? io.outCtl[0] : 0u;
+  const uint64_t longFrom = io.outCtl && io.outCtl[1] != 0xffffffffu ? uint64_t(io.outCtl[1]) : ~0ull;
+  const uint32_t outLo = uint32_t(uint64_t(nOut) * blockIdx.x / gridDim.x);
+  const uint32_t nOutW = uint32_t(uint64_t(nOut) * (blockIdx.x + 1) / gridDim.x) - outLo;
+  const uint32_t slots = nOutW + range;
 
   // current line, next line, and the claim in flight (valid for the lanes that made it)
   bool have[CH], nHave[CH], dry[CH];
@@ -339,7 +360,7 @@ k_ragged(DevDfa d, Batch io) {
   uint64_t lineOff[CH], nOff[CH];
   uint32_t tLn[CH];
   uint64_t tO[CH], tE[CH];
-  bool tHave[CH];
+  bool tHave[CH], tOut[CH];
 
   // wave-aggregated claim of one line for every (lane, chain) with want[c]; requests its offsets
   auto claim = [&](const bool (&want)[CH]) {
@@ -361,15 +382,22 @@ k_ragged(DevDfa d, Batch io) {
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(need[c] >> 32),
                                 __builtin_amdgcn_mbcnt_lo(uint32_t(need[c]), 0u));
       const uint32_t slot = base + before[c] + rank;
-      tHave[c] = want[c] && slot < range;
+      tHave[c] = want[c] && slot < slots;
       if (want[c] && !tHave[c]) dry[c] = true;
-      // unconditional requests (lanes that claimed nothing re-read entry 0)
-      const uint64_t at = tHave[c] ? lo + slot : 0;
-      tLn[c] = uint32_t(at);
-      tO[c] = io.offsets[at];
-      tE[c] = io.offsets[at + 1];
+      // unconditional requests (lanes that claimed nothing re-read entry 0): the offsets pair
+      // from the list of long lines or from offsets[], the index from the list or the slot
+      tOut[c] = tHave[c] && slot < nOutW;
+      const uint64_t at = tHave[c] && !tOut[c] ? lo + (slot - nOutW) : 0;
+      const uint64_t *pair = tOut[c] ? io.outRec + 2 * uint64_t(outLo + slot) : io.offsets + at;
+      const uint32_t *lnAt = tOut[c] ? io.outLn + (outLo + slot) : io.outLn;
+      tO[c] = pair[0];
+      tE[c] = pair[1];
+      tLn[c] = *lnAt;  // (always readable: the launcher points outLn at the pad without a list)
+      if (!tOut[c]) tLn[c] = uint32_t(at);
     }
   };
+  // a line of the contiguous range that is on the list is not this slot's to walk
+  auto passedOver = [&](int c) -> bool { return !tOut[c] && tE[c] - tO[c] >= longFrom; };
   auto lengthOf = [&](uint64_t o, uint64_t e) -> uint32_t {
     // Batch::stride doubles as "trailing delimiter bytes per line" for ragged lines
     return e - o >= io.stride ? uint32_t(e - o - io.stride) : 0u;
@@ -394,13 +422,14 @@ k_ragged(DevDfa d, Batch io) {
     claim(all);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      have[c] = tHave[c]; ln[c] = tLn[c]; lineOff[c] = have[c] ? tO[c] : 0;
+      have[c] = tHave[c] && !passedOver(c); ln[c] = tLn[c]; lineOff[c] = have[c] ? tO[c] : 0;
       len[c] = have[c] ? lengthOf(tO[c], tE[c]) : 0;
     }
     claim(all);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      nHave[c] = tHave[c]; nLn[c] = tLn[c]; nOff[c] = tO[c]; nLen[c] = lengthOf(tO[c], tE[c]);
+      nHave[c] = tHave[c] && !passedOver(c); nLn[c] = tLn[c]; nOff[c] = tO[c];
+      nLen[c] = lengthOf(tO[c], tE[c]);
     }
   }
 
@@ -530,12 +559,14 @@ k_ragged(DevDfa d, Batch io) {
     // mixed-length lines).
     uint64_t pOff[CH];
     uint32_t pLen[CH];
+    bool pHave[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       // (the empty asm keeps the compiler from hoisting this wait into the walk above)
-      asm volatile("" : "+v"(tO[c]), "+v"(tE[c]) : : "memory");
+      asm volatile("" : "+v"(tO[c]), "+v"(tE[c]), "+v"(tLn[c]) : : "memory");
       pOff[c] = tO[c];
       pLen[c] = lengthOf(tO[c], tE[c]);
+      pHave[c] = tHave[c] && !passedOver(c);
       asm volatile("" : "+v"(pOff[c]), "+v"(pLen[c]) : : "memory");
     }
 
@@ -585,7 +616,8 @@ k_ragged(DevDfa d, Batch io) {
         have[c] = nHave[c]; ln[c] = nLn[c]; lineOff[c] = nOff[c]; len[c] = nLen[c];
         done[c] = 0;
         freshLine(c);
-        nHave[c] = tHave[c]; nLn[c] = tLn[c]; nOff[c] = pOff[c]; nLen[c] = pLen[c];
+        nHave[c] = pHave[c]; nLn[c] = tLn[c]; nOff[c] = pOff[c]; nLen[c] = pLen[c];
+
       } else {
         done[c] += 64u;
       }
@@ -602,10 +634,18 @@ k_ragged(DevDfa d, Batch io) {
     for (int c = 0; c < CH; ++c) first[c] = lineOff[c];
     issueAt(A, first);
   }
+  // until no lane holds a line and none can claim one (a lane whose current and next line were
+  // both passed over holds nothing and is not dry)
+  auto busy = [&]() -> bool {
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) any = any || have[c] || nHave[c] || !dry[c];
+    return __builtin_amdgcn_ballot_w64(any) != 0;
+  };
   while (true) {
-    if (!__builtin_amdgcn_ballot_w64(have[0] || have[CH - 1])) break;
+    if (!busy()) break;
     turn(A, B);
-    if (!__builtin_amdgcn_ballot_w64(have[0] || have[CH - 1])) break;
+    if (!busy()) break;
     turn(B, A);
   }
 }
@@ -737,8 +777,9 @@ inline hipError_t raggedScratch(hipStream_t stream, size_t bytes, void **out) {
 
 // pad[0..192) = data[padStart, total) followed by zeros (see the header comment)
 __global__ void __launch_bounds__(192)
-k_tail_pad(const uint8_t *data, const uint64_t *offsets, uint64_t n, uint8_t *pad) {
-  const uint64_t total = offsets[n];
+k_tail_pad(const uint8_t *data, const uint64_t *offsets, uint64_t nMax, uint8_t *pad,
+           const uint64_t *nDev = nullptr) {
+  const uint64_t total = offsets[raggedLineCount(nMax, nDev)];
   const uint64_t padStart = total >= 128 ? total - 128 : 0;
   const uint64_t i = padStart + threadIdx.x;
   pad[threadIdx.x] = i < total ? data[i] : uint8_t(0);
@@ -770,9 +811,77 @@ inline hipError_t prepareRagged(const Batch &b, const LaunchCfg &cfg, hipStream_
                        b.stride, perBlock, hist, perm, perm + b.n);
     rb.perm = perm;
   } else {
-    hipLaunchKernelGGL(k_tail_pad, dim3(1), dim3(192), 0, stream, b.data, b.offsets, b.n, pad);
+    hipLaunchKernelGGL(k_tail_pad, dim3(1), dim3(192), 0, stream, b.data, b.offsets, b.n, pad, nullptr);
   }
   return hipGetLastError();
+}
+
+// ---- the long lines of a batch (see k_ragged's header) ---------------------------------------
+// A line is long from T = max(512, X x mean length) bytes on, delimiter bytes included; at most
+// n / X lines can be (their lengths sum to no more than the buffer), which bounds the list.  Each
+// workgroup counts the long lines of its contiguous share of offsets[], reserves that many list
+// entries with ONE atomic, and writes them in a second pass over the same (now cached) offsets.
+// Workgroup 0 also makes the tail pad (k_tail_pad's job).
+constexpr int kOutlierThreads = 256;
+constexpr uint32_t kOutlierMinBytes = 512;
+
+__global__ void __launch_bounds__(kOutlierThreads)
+k_ragged_outliers(const uint8_t *data, const uint64_t *offsets, uint64_t nMax, const uint64_t *nDev,
+                  uint32_t factor, uint32_t cap, uint8_t *pad, uint32_t *ctl, uint32_t *outLn,
+                  uint64_t *outRec) {
+  __shared__ uint32_t cnt, base, fill;
+  const uint64_t n = raggedLineCount(nMax, nDev);
+  const uint64_t total = offsets[n];
+  if (blockIdx.x == 0 && threadIdx.x < 192) {
+    const uint64_t i = (total >= 128 ? total - 128 : 0) + threadIdx.x;
+    pad[threadIdx.x] = i < total ? data[i] : uint8_t(0);
+  }
+  uint64_t T = n ? (total + n - 1) / n * factor : 0xffffffffull;
+  if (T < kOutlierMinBytes) T = kOutlierMinBytes;
+  if (T >= 0xffffffffull) T = 0xffffffffull;  // "no line is long" to k_ragged
+  if (blockIdx.x == 0 && threadIdx.x == 0) ctl[1] = uint32_t(T);
+  if (T == 0xffffffffull) return;
+  if (threadIdx.x == 0) { cnt = 0; fill = 0; }
+  __syncthreads();
+  const uint64_t lo = n * blockIdx.x / gridDim.x, hi = n * (blockIdx.x + 1) / gridDim.x;
+  uint32_t mine = 0;
+  // (four independent pairs of requests per trip: one pair per trip ran at 1.2 TB/s)
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += 4 * kOutlierThreads) {
+    uint64_t a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint64_t at = i + uint64_t(k) * kOutlierThreads;
+      a[k] = offsets[at < hi ? at : lo];
+      b[k] = offsets[at < hi ? at + 1 : lo];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mine += b[k] - a[k] >= T ? 1u : 0u;
+  }
+  for (int o = 32; o; o >>= 1) mine += __shfl_xor(mine, o);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&cnt, mine);
+  __syncthreads();
+  if (cnt == 0) return;
+  if (threadIdx.x == 0) base = atomicAdd(&ctl[0], cnt);
+  __syncthreads();
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += kOutlierThreads) {
+    const uint64_t o = offsets[i], e = offsets[i + 1];
+    if (e - o < T) continue;
+    const uint32_t k = base + atomicAdd(&fill, 1u);
+    if (k >= cap) continue;  // (cannot happen: see the bound above)
+    outLn[k] = uint32_t(i);
+    outRec[2 * uint64_t(k)] = o;
+    outRec[2 * uint64_t(k) + 1] = e;
+  }
+}
+
+// X of the rule above; REDGPU_RAGGED_LONG_X overrides it (lab; 0 = no list, >= 2 otherwise)
+inline uint32_t raggedLongFactor() {
+  static const uint32_t x = [] {
+    const char *e = getenv("REDGPU_RAGGED_LONG_X");
+    const int v = e ? atoi(e) : 4;
+    return uint32_t(v <= 0 ? 0 : v < 2 ? 2 : v > 64 ? 64 : v);
+  }();
+  return x;
 }
 
 template <int MODE, int TABK = kTabFused>
@@ -784,10 +893,39 @@ hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
   // were measured in round 3: equal lines +6-8 % (2^23 x 256 B 2.70 -> 2.93 TB/s), mixed lengths
   // -3 % (uniform 32-256: 1.60 -> 1.56), a 2^20-line batch of geometric lengths -18 %.)
   const uint64_t blocks = tiles < uint64_t(cfg.numCUs) ? tiles : uint64_t(cfg.numCUs);
-  Batch rb;
-  LaunchCfg plain = cfg;
-  plain.noBucketing = 1;  // lines are handed out in input order: nothing to sort
-  hipError_t e = prepareRagged(b, plain, stream, true, rb);
+  Batch rb = b;
+  // lines are handed out in input order, the long ones of a large batch first
+  // (REDGPU_F_NO_BUCKETING: plain input order).  Scratch: [pad 256][ctl 16][outLn u32[cap]]
+  // [outRec u64[2 cap]]
+  const uint32_t factor = raggedLongFactor();
+  const bool longFirst = factor && !cfg.noBucketing && b.n >= kBucketMinLines;
+  const uint64_t cap = longFirst ? b.n / factor + 64 : 0;
+  const size_t lnBytes = (size_t(cap) * 4 + 15) & ~size_t(15);
+  void *scratch = nullptr;
+  hipError_t e = raggedScratch(stream, 256 + 16 + lnBytes + size_t(cap) * 16, &scratch);
+  if (e != hipSuccess) return e;
+  uint8_t *pad = static_cast<uint8_t *>(scratch);
+  rb.pad = pad;
+  rb.outLn = reinterpret_cast<const uint32_t *>(pad);
+  if (longFirst) {
+    uint32_t *ctl = reinterpret_cast<uint32_t *>(pad + 256);
+    uint32_t *outLn = reinterpret_cast<uint32_t *>(pad + 256 + 16);
+    uint64_t *outRec = reinterpret_cast<uint64_t *>(pad + 256 + 16 + lnBytes);
+    e = hipMemsetAsync(ctl, 0, 16, stream);
+    if (e != hipSuccess) return e;
+    const uint64_t want = (b.n + 4095) / 4096;
+    const uint32_t nb = uint32_t(want < 2ull * uint64_t(cfg.numCUs) ? want : 2ull * uint64_t(cfg.numCUs));
+    hipLaunchKernelGGL(k_ragged_outliers, dim3(nb), dim3(kOutlierThreads), 0, stream, b.data,
+                       b.offsets, b.n, b.nDev, factor, uint32_t(cap), pad, ctl, outLn, outRec);
+    rb.outCtl = ctl;
+    rb.outLn = outLn;
+    rb.outRec = outRec;
+
+  } else {
+    hipLaunchKernelGGL(k_tail_pad, dim3(1), dim3(192), 0, stream, b.data, b.offsets, b.n, pad,
+                       b.nDev);
+  }
+  e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((k_ragged<MODE, TABK>), dim3(uint32_t(blocks)), dim3(kStreamThreads), 0,
                      stream, d, rb);

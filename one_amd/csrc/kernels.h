@@ -61,6 +61,14 @@ struct Batch {
   uint32_t *state = nullptr; // advance only: per-line StatefulMatcher state, in/out
   const uint32_t *perm = nullptr; // k_ragged only: slot -> line (lines bucketed by length)
   const uint8_t *pad = nullptr;   // k_ragged only: copy of the buffer's last 128 bytes + zeros
+  // k_ragged only: the lines much longer than the batch's mean (k_ragged_outliers), walked first
+  const uint64_t *outRec = nullptr; // [nOut][2] = the line's offsets[] pair
+  const uint32_t *outLn = nullptr;  // [nOut] = its index
+  const uint32_t *outCtl = nullptr; // [0] = nOut, [1] = the length from which a line is one
+  // k_ragged family only (launchBatch answers hipErrorNotSupported for the others): the line
+  // count is still on the device - min(*nDev, n) lines, n = what the arrays have room for
+  // (redgpu_*_text_dev: the count comes from the line split queued just before)
+  const uint64_t *nDev = nullptr;
   uint32_t spread = 1;            // k_generic only: one line per `spread` lanes (table in L2)
   uint32_t ignoreAcceptUpTo = 0;  // k_stream / k_stream_multi, check<..., true> over a forced leader:
                                   // accepts at positions <= this (the post-leader state's own
@@ -127,11 +135,13 @@ hipError_t launchReplace(const DevDfa &dfa, const Batch &b, int style, int doLea
 
 // Line splitting (lib/Util.cpp:109-130's rule): offsets[0] = 0, offsets[k+1] = position after the
 // k-th delimiter, for k < cap; *nLines = delimiters found.  counts: uint32[splitChunks(len)],
-// bases: uint64[splitChunks(len)] scratch, both device memory.
+// bases: uint64[splitChunks(len)], masks: splitMaskBytes(len) bytes (16-byte aligned) - scratch,
+// all device memory.
 uint64_t splitChunks(uint64_t len);
+uint64_t splitMaskBytes(uint64_t len);
 hipError_t launchSplitLines(const uint8_t *data, uint64_t len, uint8_t delim, uint64_t *offsets,
                             uint64_t cap, uint64_t *nLines, uint32_t *counts, uint64_t *bases,
-                            hipStream_t stream);
+                            uint16_t *masks, hipStream_t stream);
 
 // bench.py's read-bandwidth calibration: one streaming pass over `bytes` (16-byte aligned).
 hipError_t launchDiagRead(const void *data, uint64_t bytes, uint32_t *sink, int numCUs,

@@ -555,18 +555,21 @@ hipError_t launchReplace(const DevDfa &d, const Batch &b, int style, int doLeade
 
 uint64_t splitChunks(uint64_t len) { return (len + kSplitChunk - 1) / kSplitChunk; }
 
+uint64_t splitMaskBytes(uint64_t len) { return splitChunks(len) * (kSplitChunk / 8); }
+
 hipError_t launchSplitLines(const uint8_t *data, uint64_t len, uint8_t delim, uint64_t *offsets,
                             uint64_t cap, uint64_t *nLines, uint32_t *counts, uint64_t *bases,
-                            hipStream_t stream) {
+                            uint16_t *masks, hipStream_t stream) {
   const uint64_t nChunks = splitChunks(len);
+  const uint32_t groups = uint32_t((nChunks + kSplitGroup - 1) / kSplitGroup);
   if (nChunks)
-    hipLaunchKernelGGL(k_split_count, dim3(uint32_t(nChunks)), dim3(kSplitThreads), 0, stream, data,
-                       len, uint32_t(delim), counts);
+    hipLaunchKernelGGL(k_split_count, dim3(groups), dim3(kSplitThreads), 0, stream, data, len,
+                       uint32_t(delim), nChunks, counts, masks);
   hipLaunchKernelGGL(k_split_scan, dim3(1), dim3(1024), 0, stream, counts, nChunks, bases, nLines,
                      offsets, cap);
   if (nChunks)
-    hipLaunchKernelGGL(k_split_scatter, dim3(uint32_t(nChunks)), dim3(kSplitThreads), 0, stream,
-                       data, len, uint32_t(delim), bases, offsets, cap);
+    hipLaunchKernelGGL(k_split_scatter, dim3(groups), dim3(kSplitThreads), 0, stream, masks,
+                       nChunks, bases, offsets, cap);
   return hipGetLastError();
 }
 
@@ -701,6 +704,12 @@ hipError_t launchBatch(const DevDfa &d, const Batch &b, int verb, int style, int
   }
   const bool lead = doLeader && d.leaderLen > 0;
   normalizeVerbStyle(d, cfg, lead, verb, style);
+  if (b.nDev) {
+    // the line count is on the device: only the k_ragged family reads it there
+    bool handled = false;
+    hipError_t fe = launchRaggedFamily(d, b, verb, style, doLeader, cfg, stream, kernelName, &handled);
+    return handled || fe != hipSuccess ? fe : hipErrorNotSupported;
+  }
   // DFAs the visit model sees dying within 16 bytes (anchored patterns on arbitrary text) stay
   // with k_generic: the whole-line kernels below read and walk every byte, k_generic stops
   // where the reference's loop stops - measured on ERR 1.3x (64-byte lines) to 38x (4 KiB

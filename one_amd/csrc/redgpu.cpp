@@ -779,16 +779,110 @@ int redgpu_split_lines_dev(const redgpu_dfa *dfa, const uint8_t *data, uint64_t 
   hipStream_t s = static_cast<hipStream_t>(stream);
   const uint64_t nChunks = splitChunks(len);
   void *scratch = nullptr;
-  // counts u32[nChunks] then bases u64[nChunks], stream-ordered so the call stays asynchronous
+  // counts u32[nChunks], bases u64[nChunks], then the delimiter masks (2 bytes per 16 of input);
+  // stream-ordered so the call stays asynchronous
   const size_t countBytes = (size_t(nChunks) * 4 + 15) & ~size_t(15);
-  HIP_TRY(hipMallocAsync(&scratch, countBytes + size_t(nChunks) * 8 + 16, s), "hipMallocAsync");
+  const size_t headBytes = countBytes + size_t(nChunks) * 8 + 16;
+  HIP_TRY(hipMallocAsync(&scratch, headBytes + splitMaskBytes(len), s), "hipMallocAsync");
   uint32_t *counts = static_cast<uint32_t *>(scratch);
   uint64_t *bases = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(scratch) + countBytes);
-  hipError_t e = launchSplitLines(data, len, delim, offsets, cap, n_lines, counts, bases, s);
+  uint16_t *masks = reinterpret_cast<uint16_t *>(static_cast<uint8_t *>(scratch) + headBytes);
+  hipError_t e = launchSplitLines(data, len, delim, offsets, cap, n_lines, counts, bases, masks, s);
   tlsKernel = "k_split_scatter";
   hipError_t e2 = hipFreeAsync(scratch, s);
   if (e != hipSuccess) return failHip(e, "kernel launch");
   if (e2 != hipSuccess) return failHip(e2, "hipFreeAsync");
+  return REDGPU_OK;
+}
+
+// raw text -> lines -> check / match, one call, everything on `stream`
+static int textDev(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint8_t *data,
+                   uint64_t len, uint8_t delim, uint64_t *offsets, uint64_t cap, uint64_t *n_lines,
+                   int32_t *result, uint64_t *start, uint64_t *end, void *stream) {
+  if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
+  if (int rc = checkStyle(style)) return rc;
+  if (cap && !result) return fail(REDGPU_EAPI, "null result buffer");
+  if (int rc = redgpu_split_lines_dev(dfa, data, len, delim, offsets, cap, n_lines, stream)) return rc;
+  if (cap > len) cap = len;  // a buffer holds no more lines than bytes
+  if (cap == 0) return REDGPU_OK;
+  DeviceScope scope(dfa->im->device);
+  if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Batch b{data, offsets, 1, cap, result, start, end};
+  b.nDev = n_lines;
+  const LaunchCfg cfg = cfgOf(dfa);
+  const char *name = "";
+  hipError_t e = launchBatch(dfa->im->dev, b, verb, style, doLeader ? 1 : 0, cfg, s, &name);
+  if (e == hipSuccess) {
+    tlsKernel = name;
+    return REDGPU_OK;
+  }
+  if (e != hipErrorNotSupported) return failHip(e, "kernel launch");
+  (void)hipGetLastError();
+  // a kernel family that takes its line count from the host: wait for the split
+  uint64_t n = 0;
+  HIP_TRY(hipMemcpyAsync(&n, n_lines, 8, hipMemcpyDeviceToHost, s), "copy line count");
+  HIP_TRY(hipStreamSynchronize(s), "hipStreamSynchronize");
+  return runDev(dfa, verb, style, doLeader, data, offsets, 1, n < cap ? n : cap, result, start,
+                end, s);
+}
+
+int redgpu_check_text_dev(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                          uint64_t len, uint8_t delim, uint64_t *offsets, uint64_t cap,
+                          uint64_t *n_lines, int32_t *result, void *stream) {
+  return textDev(dfa, kCheck, style, do_leader, data, len, delim, offsets, cap, n_lines, result,
+                 nullptr, nullptr, stream);
+}
+
+int redgpu_match_text_dev(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                          uint64_t len, uint8_t delim, uint64_t *offsets, uint64_t cap,
+                          uint64_t *n_lines, int32_t *result, uint64_t *start, uint64_t *end,
+                          void *stream) {
+  return textDev(dfa, kMatch, style, do_leader, data, len, delim, offsets, cap, n_lines, result,
+                 start, end, stream);
+}
+
+// host-buffer form: one upload, split + verb on the device, the filled prefixes back
+int redgpu_match_text(const redgpu_dfa *dfa, int style, int do_leader, const uint8_t *data,
+                      uint64_t len, uint8_t delim, uint64_t *offsets, uint64_t cap,
+                      uint64_t *n_lines, int32_t *result, uint64_t *start, uint64_t *end) {
+  if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
+  if (dfa->im->device < 0) return fail(REDGPU_EAPI, "dfa handle has no device image");
+  if (!n_lines) return fail(REDGPU_EAPI, "null output buffer");
+  if (cap && (!offsets || !result)) return fail(REDGPU_EAPI, "null output buffer");
+  if (len && !data) return fail(REDGPU_EAPI, "null data buffer");
+  DeviceScope scope(dfa->im->device);
+  if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
+  HostStage *st = nullptr;
+  if (int rc = stageOf(dfa, &st)) return rc;
+  hipStream_t s = st->streams[0];
+  if (cap > len) cap = len;
+  uint8_t *dData = nullptr;
+  uint64_t *dOff = nullptr, *dN = nullptr, *dStart = nullptr, *dEnd = nullptr;
+  int32_t *dRes = nullptr;
+  STAGE_TRY(st->get(kSlData, len, reinterpret_cast<void **>(&dData)), "hipMalloc data");
+  STAGE_TRY(st->get(kSlAux0, 8, reinterpret_cast<void **>(&dN)), "hipMalloc count");
+  STAGE_TRY(st->get(kSlOff, (cap + 1) * 8, reinterpret_cast<void **>(&dOff)), "hipMalloc offsets");
+  STAGE_TRY(st->get(kSlRes, cap * 4, reinterpret_cast<void **>(&dRes)), "hipMalloc result");
+  if (start) STAGE_TRY(st->get(kSlStart, cap * 8, reinterpret_cast<void **>(&dStart)), "hipMalloc start");
+  if (end) STAGE_TRY(st->get(kSlEnd, cap * 8, reinterpret_cast<void **>(&dEnd)), "hipMalloc end");
+  if (len) STAGE_TRY(hipMemcpyAsync(dData, data, len, hipMemcpyHostToDevice, s), "copy data");
+  const int rc = textDev(dfa, start || end ? kMatch : kCheck, style, do_leader, dData, len, delim,
+                         dOff, cap, dN, dRes, dStart, dEnd, s);
+  if (rc != REDGPU_OK) {
+    (void)st->sync();
+    return rc;
+  }
+  STAGE_TRY(hipMemcpyAsync(n_lines, dN, 8, hipMemcpyDeviceToHost, s), "copy count");
+  STAGE_TRY(hipStreamSynchronize(s), "hipStreamSynchronize");
+  const uint64_t got = *n_lines < cap ? *n_lines : cap;
+  if (cap) STAGE_TRY(hipMemcpyAsync(offsets, dOff, (got + 1) * 8, hipMemcpyDeviceToHost, s), "copy offsets");
+  if (got) {
+    STAGE_TRY(hipMemcpyAsync(result, dRes, got * 4, hipMemcpyDeviceToHost, s), "copy result");
+    if (start) STAGE_TRY(hipMemcpyAsync(start, dStart, got * 8, hipMemcpyDeviceToHost, s), "copy start");
+    if (end) STAGE_TRY(hipMemcpyAsync(end, dEnd, got * 8, hipMemcpyDeviceToHost, s), "copy end");
+  }
+  STAGE_TRY(hipStreamSynchronize(s), "hipStreamSynchronize");
   return REDGPU_OK;
 }
 

@@ -600,6 +600,61 @@ def split_lines(exe, data, delim=b"\n", cap=None):
     return offs[: min(cnt.value, cap) + 1], int(cnt.value)
 
 
+def match_text(exe, data, style, do_leader=True, *, delim=b"\n", cap=None, want_start=True,
+               want_end=True):
+    """redgpu_match_text[_dev]: the delimiter-terminated lines of a raw text buffer, each
+    matched (tools/skim_red.cpp:36-46 over lib/Util.cpp:109-130's lines), in one call.
+    Host input -> (offsets uint64[k+1], n_found, result int32[k], start | None, end | None) with
+    k = min(n_found, cap); cap=None sizes the arrays with a counting call first.
+    A CUDA uint8 tensor -> (offsets int64[cap+1], count int64[1], result int32[cap], start, end)
+    tensors, asynchronously on the current stream; entries from min(count, cap) on are untouched.
+    want_start = want_end = False is check<style,doLeader>."""
+    l = _lib.lib()
+    d = delim[0] if isinstance(delim, (bytes, bytearray)) else int(delim)
+    if _is_torch(data):
+        import torch
+        if not data.is_cuda or data.dtype != torch.uint8 or not data.is_contiguous():
+            raise RedExceptApi("device input must be a contiguous uint8 CUDA tensor")
+        if cap is None:
+            raise RedExceptApi("device match_text needs cap (room in the output tensors)")
+        dev = data.device
+        offs = torch.empty(cap + 1, dtype=torch.int64, device=dev)
+        cnt = torch.empty(1, dtype=torch.int64, device=dev)
+        res = torch.empty(cap, dtype=torch.int32, device=dev)
+        st = torch.empty(cap, dtype=torch.int64, device=dev) if want_start else None
+        en = torch.empty(cap, dtype=torch.int64, device=dev) if want_end else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if st is None and en is None:
+            _check(l.redgpu_check_text_dev(exe._h, int(style), 1 if do_leader else 0,
+                                           data.data_ptr(), data.numel(), d, offs.data_ptr(), cap,
+                                           cnt.data_ptr(), res.data_ptr(), stream))
+        else:
+            _check(l.redgpu_match_text_dev(exe._h, int(style), 1 if do_leader else 0,
+                                           data.data_ptr(), data.numel(), d, offs.data_ptr(), cap,
+                                           cnt.data_ptr(), res.data_ptr(),
+                                           st.data_ptr() if st is not None else None,
+                                           en.data_ptr() if en is not None else None, stream))
+        return offs, cnt, res, st, en
+    a = _host_u8(data)
+    dp = a.ctypes.data if a.size else None
+    cnt = C.c_uint64(0)
+    if cap is None:
+        one = np.zeros(1, dtype=np.uint64)
+        _check(l.redgpu_split_lines(exe._h, dp, a.size, d, one.ctypes.data, 0, C.byref(cnt)))
+        cap = int(cnt.value)
+    offs = np.zeros(cap + 1, dtype=np.uint64)
+    res = np.zeros(cap, dtype=np.int32)
+    st = np.zeros(cap, dtype=np.uint64) if want_start else None
+    en = np.zeros(cap, dtype=np.uint64) if want_end else None
+    _check(l.redgpu_match_text(exe._h, int(style), 1 if do_leader else 0, dp, a.size, d,
+                               offs.ctypes.data, cap, C.byref(cnt), res.ctypes.data,
+                               st.ctypes.data if st is not None else None,
+                               en.ctypes.data if en is not None else None))
+    k = min(int(cnt.value), cap)
+    return (offs[:k + 1], int(cnt.value), res[:k], st[:k] if st is not None else None,
+            en[:k] if en is not None else None)
+
+
 class StatefulMatcher:
     """Mirror of zezax::red::StatefulMatcher (include/Matcher.h:770-792): `advance(byte)` and
     `result()`; `advance_bytes` feeds a whole chunk in one kernel launch.  The executable must

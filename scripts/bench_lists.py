@@ -1,6 +1,6 @@
 """GB/s of the "next row" verbs: StatefulMatcher chunks (advance), matchAll,
 collect, search - one stream, inputs resident.  Developer tool (bench.py is the contract bench).
-usage: bench_lists.py [dfa-name]"""
+usage: bench_lists.py [dfa-name]      (TEXT_ONLY=1: only the raw-text section)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C
@@ -25,7 +25,8 @@ def timed(fn, it):
     return a.elapsed_time(b) / it
 
 
-for n, L in [(1 << 20, 64), (1 << 18, 4096), (1 << 20, 96)]:
+TEXT_ONLY = bool(os.environ.get("TEXT_ONLY"))
+for n, L in [] if TEXT_ONLY else [(1 << 20, 64), (1 << 18, 4096), (1 << 20, 96)]:
     total = n * L
     data = torch.randint(0, 256, (total,), dtype=torch.uint8, device="cuda")
     state = torch.full((n,), -1, dtype=torch.int32, device="cuda")
@@ -51,15 +52,22 @@ for n, L in [(1 << 20, 64), (1 << 18, 4096), (1 << 20, 96)]:
 # line splitting on the device, then matching the split lines (delimiter dropped)
 import numpy as np
 from one_amd import workloads as W
-for total, p_nl in ((1 << 26, 1 / 64), (1 << 28, 1 / 144)):
+for total, p_nl in ((1 << 26, 1 / 64), (1 << 28, 1 / 144), (1 << 28, None)):
     host = W.alphabet_bytes(total, 12).copy()
     rng = np.random.default_rng(1)
-    host[rng.random(total) < p_nl] = 0x0A
+    if p_nl is None:   # line lengths uniform in 32..256 instead of geometric
+        ends = np.cumsum(rng.integers(33, 258, total // 100))
+        host[ends[ends < total]] = 0x0A
+        label = "uniform 32-256 B lines"
+    else:
+        host[rng.random(total) < p_nl] = 0x0A
+        label = "geometric lines, mean %d B" % round(1 / p_nl)
     dev = torch.from_numpy(host).cuda()
-    cap = int(total * p_nl * 1.2) + 16
+    cap = int(total * (p_nl or 1 / 120) * 1.2) + 16
     ms = timed(lambda: one_amd.split_lines(exe, dev, cap=cap), 20)
     offs, cnt = one_amd.split_lines(exe, dev, cap=cap)
     n = int(cnt.item())
+    print("text: %s" % label)
     print("split     %9d bytes -> %8d lines  %8.1f us  %7.1f GB/s" % (total, n, ms * 1e3, total / ms / 1e6), flush=True)
     o = offs[:n + 1].contiguous()
     res = torch.empty(n, dtype=torch.int32, device="cuda")
@@ -67,6 +75,8 @@ for total, p_nl in ((1 << 26, 1 / 64), (1 << 28, 1 / 144)):
     en = torch.empty(n, dtype=torch.int64, device="cuda")
     ms = timed(lambda: one_amd.match_batch(exe, dev, 4, False, offsets=o, stride=1, out=(res, st, en)), 20)
     print("match     same lines (delimiter dropped)      %8.1f us  %7.1f GB/s  %s" % (ms * 1e3, total / ms / 1e6, one_amd.last_kernel()), flush=True)
+    ms = timed(lambda: one_amd.match_text(exe, dev, 4, False, cap=cap), 20)
+    print("match_text (split + match in one call)        %8.1f us  %7.1f GB/s  %s" % (ms * 1e3, total / ms / 1e6, one_amd.last_kernel()), flush=True)
     del dev
 
 # replace<styLast,false> on device-resident lines (redgpu_replace_batch_dev): count pass, prefix sum
@@ -76,7 +86,7 @@ import os as _os, sys as _sys
 _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
 from golden_util import load_dfa as _ld
 uexe = one_amd.Executable(_ld("uri"))
-for n, L in ((1 << 20, 64), (1 << 18, 1024)):
+for n, L in () if TEXT_ONLY else ((1 << 20, 64), (1 << 18, 1024)):
     host = W.fixed_lines(n, L, 5, plant=W.URI_PLANT, plant_every=4, plant_at=8)
     dev = torch.from_numpy(host).cuda()
     repl = torch.from_numpy(np.frombuffer(b"<url>", dtype=np.uint8).copy()).cuda()

@@ -8,6 +8,7 @@ run() { echo "## scripts/$*" >> $L; timeout -k 10 300 python3 $R/scripts/$* 2>&1
 run bench_shapes.py
 run bench_generic.py
 run bench_lists.py
+TEXT_ONLY=1 run bench_lists.py uri
 run bench_scan.py
 run bench_anchored.py
 run bench_longlines.py syn4k

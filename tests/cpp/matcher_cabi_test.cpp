@@ -59,6 +59,20 @@ int main(int argc, char **argv) {
     EXPECT_EQ(2, ocs[2].result_);
     EXPECT_EQ(size_t(15), ocs[2].end_);
     EXPECT_EQ(0, ocs[3].result_);
+    // the same lines as one text blob (tools/skim_red.cpp:36-46; the tail without a delimiter
+    // is not a line: lib/Util.cpp:109-130)
+    std::vector<size_t> starts;
+    std::vector<Outcome> tx = matchText(rex, "New\nnothing here\nI love New York.\n\nNew York", styLast,
+                                        true, '\n', &starts);
+    EXPECT_EQ(size_t(4), tx.size());
+    EXPECT_EQ(1, tx[0].result_);
+    EXPECT_EQ(0, tx[1].result_);
+    EXPECT_EQ(2, tx[2].result_);
+    EXPECT_EQ(size_t(7), tx[2].start_);
+    EXPECT_EQ(size_t(15), tx[2].end_);
+    EXPECT_EQ(0, tx[3].result_);
+    EXPECT_EQ(size_t(17), starts[2]);
+    EXPECT_EQ(size_t(0), matchText(rex, "no delimiter at all", styLast).size());
   }
   // test/matcher.cpp:695-723 matchAll
   {

@@ -881,6 +881,69 @@ def test_split_lines_on_device_then_match():
     assert np.array_equal(e.cpu().numpy().astype(np.uint64), ee)
 
 
+@pytest.mark.parametrize("name", ["uri", "syn256", "uri_v6", "log100", "err", "newyork4"])
+def test_match_text_one_call(name):
+    """redgpu_match_text[_dev]: raw text -> lines (lib/Util.cpp:109-130) -> match / check per line
+    (tools/skim_red.cpp:36-46) in one call, against oracle.split_lines + CpuOracle on the lines
+    with their delimiters removed.  Buffers: empty; one delimiter; runs of empty lines; no
+    trailing delimiter; nothing but delimiters; no delimiter at all; a line far longer than the
+    rest; > 16384 lines (the long-lines list of k_ragged is in play).  cap below the number of
+    lines keeps the first cap and still reports the count.  DFAs: the k_ragged family reads the
+    line count on the device (uri, syn256, uri_v6 hot rows); log100 / err (die early: k_early,
+    k_generic) and newyork4 take the count through the host."""
+    import torch
+    blob = load_dfa(name)
+    exe, cpu = one_amd.Executable(blob), O.CpuOracle(blob)
+    rng = np.random.default_rng(31)
+    plant = np.frombuffer(W.URI_PLANT, dtype=np.uint8)
+    shapes = [(0, 0.1), (1, 1.0), (15, 0.3), (5000, 0.05), (70000, 0.0), (30000, 1.0),
+              (2_500_001, 0.008), (1_500_000, 0.02)]
+    for k, (n_bytes, p_nl) in enumerate(shapes):
+        text = (W.random_bytes if name == "syn256" else W.alphabet_bytes)(n_bytes + 3, 91 + k)[3:].copy()
+        text[text == 0x0A] = 0x20
+        text[rng.random(n_bytes) < p_nl] = 0x0A
+        if n_bytes > 1_000_000:
+            text[200000:260000][text[200000:260000] == 0x0A] = 0x2E     # one 60 KB line
+        if n_bytes > 200 and name != "syn256":
+            for at in range(0, n_bytes - 100, 499):
+                text[at:at + len(plant)] = plant
+        exp = O.split_lines(text)
+        n = len(exp) - 1
+        keep = text[:int(exp[-1])]
+        compact = keep[keep != 0x0A]
+        coffs = exp - np.arange(n + 1, dtype=np.uint64)
+        for si, lead in ((4, 0), (5, 0), (4, 1)):
+            er, es, ee = cpu.batch("match", si, lead, compact, offsets=coffs, threads=4)
+            offs, found, r, s, e = one_amd.match_text(exe, text, si, lead)
+            assert found == n and np.array_equal(offs, exp), (name, n_bytes)
+            assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee), \
+                (name, n_bytes, p_nl, si, lead)
+            # device form, cap above and below the number of lines; check = no positions
+            dev = torch.from_numpy(np.ascontiguousarray(text)).cuda()
+            for cap in (n + 7, max(1, n // 3)):
+                doffs, dcnt, dr, ds, de = one_amd.match_text(exe, dev, si, lead, cap=cap)
+                got = min(n, cap)
+                torch.cuda.synchronize()
+                assert int(dcnt.item()) == n
+                assert np.array_equal(doffs[:got + 1].cpu().numpy().astype(np.uint64), exp[:got + 1])
+                assert np.array_equal(dr[:got].cpu().numpy(), er[:got])
+                assert np.array_equal(ds[:got].cpu().numpy().astype(np.uint64), es[:got])
+                assert np.array_equal(de[:got].cpu().numpy().astype(np.uint64), ee[:got])
+                _, _, cr, cs, ce = one_amd.match_text(exe, dev, si, lead, cap=cap, want_start=False,
+                                                      want_end=False)
+                assert cs is None and ce is None
+                ec = cpu.batch("check", si, lead, compact, offsets=coffs, threads=4)[0]
+                assert np.array_equal(cr[:got].cpu().numpy(), ec[:got]), (name, n_bytes, si, lead)
+    # entries past the lines found are left alone
+    dev = torch.from_numpy(np.frombuffer(b"ab\ncd\nxyz", dtype=np.uint8).copy()).cuda()
+    doffs, dcnt, dr, ds, de = one_amd.match_text(exe, dev, 4, 0, cap=5)
+    torch.cuda.synchronize()
+    assert int(dcnt.item()) == 2 and doffs[:3].tolist() == [0, 3, 6]
+    if name in ("uri", "syn256", "uri_v6"):
+        one_amd.match_text(exe, torch.zeros(1 << 20, dtype=torch.uint8, device="cuda"), 4, 0, cap=10)
+        assert one_amd.last_kernel().startswith("k_ragged"), one_amd.last_kernel()
+
+
 @pytest.mark.parametrize("name", ["syn256", "uri"])
 def test_ragged_length_bucketing_vs_oracle(name):
     """k_ragged behind its length-bucketing pass (>= 16384 lines): skewed line lengths - many
@@ -1317,6 +1380,66 @@ def test_ragged_stream_kernel_tail_and_shapes(name):
                                   cpu.batch("check", si, 0, data, offsets=offsets)[0])
     one_amd.match_batch(exe, data, 4, 0, offsets=offsets)
     assert one_amd.last_kernel().startswith("k_ragged")
+
+
+@pytest.mark.parametrize("name", ["syn256", "uri", "uri_v6"])
+def test_ragged_long_lines_first(name):
+    """k_ragged with k_ragged_outliers' list (batches of >= 16384 lines): lines of at least
+    max(512, 4 x mean) bytes are walked first, out of input order, and passed over in the
+    workgroup's contiguous range.  Shapes: geometric lengths; a RUN of long lines (every lane of a
+    wave finds its current and its next line passed over); long lines at the very start / end; one
+    line that holds most of the buffer; lengths right at the threshold; and the same batches with
+    REDGPU_F_NO_BUCKETING (plain input order) must give the same arrays."""
+    blob = load_dfa(name)
+    cpu = O.CpuOracle(blob)
+    exe = one_amd.Executable(blob)
+    exe_plain = one_amd.Executable(blob, no_bucketing=True)
+    rng = np.random.default_rng(23)
+    n = 20000
+    geo = np.minimum(rng.geometric(1.0 / 90.0, n), 6000)
+    run = rng.integers(0, 60, n)
+    run[7000:7400] = 2000                      # 400 consecutive long lines, mean ~70 -> T = 512
+    ends = rng.integers(0, 100, n)
+    ends[:3] = 3000
+    ends[-3:] = 2500
+    one = rng.integers(0, 30, n)
+    one[n // 2] = 600000                       # mean ~45 bytes, T = 512 ... and one huge line
+    # mean exactly 128 -> T = 512: lengths 511 / 512 / 513 sit on both sides of the rule
+    edge = np.full(n, 128, dtype=np.int64)
+    edge[100:100 + 3 * 40:3] = 511
+    edge[101:101 + 3 * 40:3] = 512
+    edge[102:102 + 3 * 40:3] = 513
+    edge[5000:5000 + 960] -= 48                # ... which the 120 lines above exceed by 40 x 1152
+    assert edge.sum() == 128 * n
+    shapes = {"geometric": geo, "run": run, "ends": ends, "one": one, "edge": edge}
+    if name == "uri_v6":
+        shapes = {"geometric": geo, "run": run}
+    for label, lens in shapes.items():
+        lens = np.asarray(lens, dtype=np.int64)
+        offsets = np.zeros(len(lens) + 1, dtype=np.uint64)
+        offsets[1:] = np.cumsum(lens)
+        total = int(offsets[-1])
+        data = W.fixed_lines(1, total, 29, alphabet=(name != "syn256"),
+                             plant=b" see http://a.bc/x and https://[2001:db8::1]/ " if name != "syn256" else None,
+                             plant_every=1, plant_at=0)[:total]
+        for si in (4, 5):
+            er, es, ee = cpu.batch("match", si, 0, data, offsets=offsets)
+            for ex in (exe, exe_plain):
+                r, s, e = one_amd.match_batch(ex, data, si, 0, offsets=offsets)
+                assert one_amd.last_kernel().startswith("k_ragged"), one_amd.last_kernel()
+                assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee), \
+                    (name, label, si)
+            assert np.array_equal(one_amd.check_batch(exe, data, si, 0, offsets=offsets),
+                                  cpu.batch("check", si, 0, data, offsets=offsets)[0]), (name, label)
+        # delimiter-terminated lines (stride = 1 trailing byte): the rule counts the raw length
+        if label == "geometric":
+            keep = np.ones(total, dtype=bool)
+            keep[(offsets[1:][lens > 0] - np.uint64(1)).astype(np.int64)] = False
+            coffs = np.zeros(len(lens) + 1, dtype=np.uint64)
+            coffs[1:] = np.cumsum(np.maximum(lens - 1, 0))
+            er, es, ee = cpu.batch("match", 4, 0, data[keep], offsets=coffs)
+            r, s, e = one_amd.match_batch(exe, data, 4, 0, offsets=offsets, stride=1)
+            assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee)
 
 
 def test_match_all_on_gpu():

@@ -118,7 +118,10 @@ for src in sorted(glob.glob(os.path.join(root, "gpurun_out", "prof_r03_c*"))):
     if c.get("TCC_REQ_sum"):
         summary["l2_requests_per_us"] = c["TCC_REQ_sum"] / (float(dom["AverageNs"]) / 1e3)
     # input bytes of one launch of the dominant kernel, from the shape of the config
-    shape = {"1": (1 << 20) * 64, "2": (1 << 21) * 4096, "4": (1 << 16) * (1 << 16)}.get(cfg)
+    # (config 3: the seeded 2^23 ragged lines of 32..256 B bench.py generates - its
+    # roofline.input_bytes_per_launch)
+    shape = {"1": (1 << 20) * 64, "2": (1 << 21) * 4096, "3": 1208234691,
+             "4": (1 << 16) * (1 << 16)}.get(cfg)
     bpl = 20 if (cfg == "1" and "multi" in kname) else 1
     summary["batches_per_launch"] = bpl
     if shape:

@@ -436,19 +436,26 @@ def main():
     plans = {}
     host_trace = []
 
-    def plan_of(count):
+    def plan_of(count, per=None):
         """the multi-batch calls of `count` steps: (descriptor window, steps in it), built once"""
-        if count not in plans:
-            plans[count] = [(window(i, min(per_call, count - i)), min(per_call, count - i), i)
-                            for i in range(0, count, per_call)]
-        return plans[count]
+        per = per or per_call
+        if (count, per) not in plans:
+            plans[(count, per)] = [(window(i, min(per, count - i)), min(per, count - i), i)
+                                   for i in range(0, count, per)]
+        return plans[(count, per)]
 
-    def run_steps(count):
+    # The warm-up steps go out two per call: the host side of a launch (HIP's launch path, the
+    # library's) costs ~3 us when it has just run and 20-50 us when it has not (scripts/lab/
+    # host_issue.py: 3.1 us back to back, 7-11 us after 50 ms, 32-48 us after 0.5 s), and W steps
+    # in one call would leave the timed call as the second launch of the process.
+    warm_per = 2 if per_call > 1 else None
+
+    def run_steps(count, per=None):
         """`count` steps, the way this run issues them; returns the last step's outputs"""
         if per_call > 1:
             h, sty, lead = wl.exe._h, wl.style, wl.lead
             ta = time.perf_counter()
-            for win, cnt, i in plan_of(count):
+            for win, cnt, i in plan_of(count, per):
                 if fn_many(h, sty, lead, win, cnt, cur_stream) != 0:
                     raise RuntimeError(_lib.lib().redgpu_last_error().decode())
             host_trace[:] = [ta, time.perf_counter()]
@@ -497,12 +504,12 @@ def main():
 
     if per_call > 1:  # the timed loop's descriptor windows, before any clock starts
         plan_of(args.steps)
-        plan_of(args.warmup)
+        plan_of(args.warmup, warm_per)
     # (the two events exist - torch creates the HIP event at its first record() - before any clock
     # starts: creating them inside the timed region cost ~50 us of a 0.4 ms region)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
-    run_steps(args.warmup)
+    run_steps(args.warmup, warm_per)
     ev1.record()
     if streams is not None:
         for st in streams:

@@ -35,3 +35,24 @@ print("torch event record                     :", t(lambda: ev.record(), reps=50
 print("torch.cuda.synchronize (idle)          :", t(lambda: torch.cuda.synchronize(), sync_each=False))
 x = torch.zeros(1, device="cuda")
 print("torch tiny kernel launch (x.add_(1))   :", t(lambda: x.add_(1), reps=50))
+# the first calls of a process, one by one (bench.py's timed call is the second multi-batch call
+# of its process), then calls that follow an idle pause
+def one(cnt):
+    torch.cuda.synchronize()
+    a = time.perf_counter(); l.redgpu_match_batches_dev(exe._h, 4, 0, descs, cnt, st); b = time.perf_counter()
+    torch.cuda.synchronize()
+    return (b - a) * 1e6
+print("fresh shapes, call by call (us): 5 batches %.1f, then 20 batches %s" % (one(5), ["%.1f" % one(20) for _ in range(6)]))
+for pause in (0.0, 0.005, 0.05, 0.5):
+    xs = []
+    for _ in range(5):
+        time.sleep(pause)
+        xs.append(one(20))
+    print("after %.3f s idle: %s" % (pause, ["%.1f" % v for v in xs]))
+ev0 = torch.cuda.Event(enable_timing=True)
+xs = []
+for _ in range(5):
+    torch.cuda.synchronize(); ev0.record()
+    a = time.perf_counter(); l.redgpu_match_batches_dev(exe._h, 4, 0, descs, K, st); b = time.perf_counter()
+    xs.append((b - a) * 1e6)
+print("right behind an event record: %s" % ["%.1f" % v for v in xs])

@@ -267,7 +267,9 @@ __device__ __noinline__ SlowBook slowRagged(const DevDfa &d, const uint8_t *tab8
 //    lines of at least `outCtl[1]` bytes (a multiple of the batch's mean length, so they are few);
 //    every workgroup takes its share of that list FIRST - slots [0, nOutW) of its cursor - and
 //    then its contiguous range, in which those lines are passed over.  The long lines so run
-//    beside the bulk instead of after it, and the tail is at most the threshold long.
+//    beside the bulk instead of after it, and the tail is at most the threshold long;
+//  * a huge line (8 x that threshold and more) is listed as PIECES that are walked at once, for
+//    DFAs whose state a 64-byte lead-in predicts (see k_ragged_outliers): `kind`, `ent` below.
 // =========================================================================================
 template <int MODE, int TABK = kTabFused>
 __global__ void __launch_bounds__(kStreamThreads)
@@ -350,8 +352,9 @@ k_ragged(DevDfa d, Batch io) {
   // the long lines: this workgroup's share of the list, and the length that makes a line one
   const uint32_t nOut = io.outCtl ? io.outCtl[0] : 0u;
   const uint64_t longFrom = io.outCtl && io.outCtl[1] != 0xffffffffu ? uint64_t(io.outCtl[1]) : ~0ull;
-  const uint32_t outLo = uint32_t(uint64_t(nOut) * blockIdx.x / gridDim.x);
-  const uint32_t nOutW = uint32_t(uint64_t(nOut) * (blockIdx.x + 1) / gridDim.x) - outLo;
+  // (entry w, w + G, w + 2 G ... of the list: the pieces of one huge line are neighbours in it and
+  // so spread over all workgroups)
+  const uint32_t nOutW = nOut > blockIdx.x ? (nOut - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
   const uint32_t slots = nOutW + range;
 
   // current line, next line, and the claim in flight (valid for the lanes that made it)
@@ -361,6 +364,9 @@ k_ragged(DevDfa d, Batch io) {
   uint32_t tLn[CH];
   uint64_t tO[CH], tE[CH];
   bool tHave[CH], tOut[CH];
+  // pieces (fused tables only): 0 = a whole line, 2 = a piece, 3 = a piece whose first block is
+  // the 64 bytes in front of it, walked from the initial state to guess its entry state
+  uint32_t kind[CH], nKind[CH], tKind[CH], ent[CH];
 
   // wave-aggregated claim of one line for every (lane, chain) with want[c]; requests its offsets
   auto claim = [&](const bool (&want)[CH]) {
@@ -388,8 +394,9 @@ k_ragged(DevDfa d, Batch io) {
       // from the list of long lines or from offsets[], the index from the list or the slot
       tOut[c] = tHave[c] && slot < nOutW;
       const uint64_t at = tHave[c] && !tOut[c] ? lo + (slot - nOutW) : 0;
-      const uint64_t *pair = tOut[c] ? io.outRec + 2 * uint64_t(outLo + slot) : io.offsets + at;
-      const uint32_t *lnAt = tOut[c] ? io.outLn + (outLo + slot) : io.outLn;
+      const uint64_t entry = uint64_t(blockIdx.x) + uint64_t(slot) * gridDim.x;
+      const uint64_t *pair = tOut[c] ? io.outRec + 2 * entry : io.offsets + at;
+      const uint32_t *lnAt = tOut[c] ? io.outLn + entry : io.outLn;
       tO[c] = pair[0];
       tE[c] = pair[1];
       tLn[c] = *lnAt;  // (always readable: the launcher points outLn at the pad without a list)
@@ -398,6 +405,11 @@ k_ragged(DevDfa d, Batch io) {
   };
   // a line of the contiguous range that is on the list is not this slot's to walk
   auto passedOver = [&](int c) -> bool { return !tOut[c] && tE[c] - tO[c] >= longFrom; };
+  // the two top bits of a list entry's end say what it is (offsets stay far below 2^62)
+  auto takeKind = [&](int c) {
+    tKind[c] = IDXD ? 0u : uint32_t(tE[c] >> 62);
+    if (!IDXD) tE[c] &= (1ull << 62) - 1;
+  };
   auto lengthOf = [&](uint64_t o, uint64_t e) -> uint32_t {
     // Batch::stride doubles as "trailing delimiter bytes per line" for ragged lines
     return e - o >= io.stride ? uint32_t(e - o - io.stride) : 0u;
@@ -407,7 +419,7 @@ k_ragged(DevDfa d, Batch io) {
   uint32_t g[CH];  // HOT: global id of the lane's state while it is outside the hot set
   uint64_t mA[CH], mB[CH], vA[CH], vB[CH];
   auto freshLine = [&](int c) {
-    s[c] = init; accS[c] = 0; endv[c] = 0; startv[c] = 0; g[c] = kNoState;
+    s[c] = init; accS[c] = 0; endv[c] = 0; startv[c] = 0; g[c] = kNoState; ent[c] = init;
     if (HOT && init == 0x1ffu) { s[c] = 255u; g[c] = d.init; }
   };
 #pragma unroll
@@ -422,14 +434,18 @@ k_ragged(DevDfa d, Batch io) {
     claim(all);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
+      takeKind(c);
       have[c] = tHave[c] && !passedOver(c); ln[c] = tLn[c]; lineOff[c] = have[c] ? tO[c] : 0;
       len[c] = have[c] ? lengthOf(tO[c], tE[c]) : 0;
+      kind[c] = tHave[c] ? tKind[c] : 0u;
     }
     claim(all);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
+      takeKind(c);
       nHave[c] = tHave[c] && !passedOver(c); nLn[c] = tLn[c]; nOff[c] = tO[c];
       nLen[c] = lengthOf(tO[c], tE[c]);
+      nKind[c] = tHave[c] ? tKind[c] : 0u;
     }
   }
 
@@ -550,6 +566,12 @@ k_ragged(DevDfa d, Batch io) {
         const bool wasInit63 = (mA[c] >> lane) & 1;
         if (full && wasInit63 && s[c] != init) startv[c] = off + 63;
       }
+      // a piece's lead-in block is behind it: what it arrived in is the guess of its entry state,
+      // and nothing seen on the way belongs to the piece
+      if (!IDXD && (kind[c] & 1u) && off == 0) {
+        ent[c] = s[c];
+        accS[c] = 0; endv[c] = 0; startv[c] = 0;
+      }
     }
 
     // The claimed lines' offsets (requested at the top of the turn) are taken BEFORE this turn's
@@ -564,6 +586,7 @@ k_ragged(DevDfa d, Batch io) {
     for (int c = 0; c < CH; ++c) {
       // (the empty asm keeps the compiler from hoisting this wait into the walk above)
       asm volatile("" : "+v"(tO[c]), "+v"(tE[c]), "+v"(tLn[c]) : : "memory");
+      takeKind(c);
       pOff[c] = tO[c];
       pLen[c] = lengthOf(tO[c], tE[c]);
       pHave[c] = tHave[c] && !passedOver(c);
@@ -603,17 +626,25 @@ k_ragged(DevDfa d, Batch io) {
         }
         const uint64_t at = ln[c];
         uint8_t *dummy = const_cast<uint8_t *>(io.pad) + 192;
-        int32_t *rp = report ? io.result + at : reinterpret_cast<int32_t *>(dummy);
-        *rp = rr;
-        uint64_t *ep = report && io.end ? io.end + at : reinterpret_cast<uint64_t *>(dummy);
-        *ep = rr ? uint64_t(en) : 0;
+        // a piece leaves its record where a line leaves its Outcome: the same three stores
+        const bool piece = !IDXD && (kind[c] & 2u);
+        const int32_t rec = int32_t((endv[c] ? accS[c] : 0u) | (ent[c] << 8) | (s[c] << 16) |
+                                    (endv[c] ? 1u << 24 : 0u));
+        int32_t *rp = report ? (piece ? io.pieceRes : io.result) + at : reinterpret_cast<int32_t *>(dummy);
+        *rp = piece ? rec : rr;
+        uint64_t *endTo = piece ? io.pieceEnd : io.end;
+        uint64_t *ep = report && endTo ? endTo + at : reinterpret_cast<uint64_t *>(dummy);
+        *ep = piece ? uint64_t(endv[c]) : rr ? uint64_t(en) : 0;
         if (kStart) {
-          uint64_t *sp = report && io.start ? io.start + at : reinterpret_cast<uint64_t *>(dummy);
-          *sp = rr ? uint64_t(st) : 0;
+          uint64_t *startTo = piece ? io.pieceStart : io.start;
+          uint64_t *sp = report && startTo ? startTo + at : reinterpret_cast<uint64_t *>(dummy);
+          *sp = piece ? uint64_t(startv[c]) : rr ? uint64_t(st) : 0;
         }
       }
       if (ends[c]) {
         have[c] = nHave[c]; ln[c] = nLn[c]; lineOff[c] = nOff[c]; len[c] = nLen[c];
+        kind[c] = nKind[c];
+        nKind[c] = tHave[c] ? tKind[c] : 0u;
         done[c] = 0;
         freshLine(c);
         nHave[c] = pHave[c]; nLn[c] = tLn[c]; nOff[c] = pOff[c]; nLen[c] = pLen[c];
@@ -822,14 +853,41 @@ inline hipError_t prepareRagged(const Batch &b, const LaunchCfg &cfg, hipStream_
 // workgroup counts the long lines of its contiguous share of offsets[], reserves that many list
 // entries with ONE atomic, and writes them in a second pass over the same (now cached) offsets.
 // Workgroup 0 also makes the tail pad (k_tail_pad's job).
+//
+// PIECES (`pieces` != 0: fused-u8 tables of DFAs that forget their past).  Even started first, a
+// line is walked by one lane at ~105 ns per byte: 2 KB - the longest of 2^20 geometric lines of
+// mean 144 - are 210 us, a megabyte of minified JSON in a log is 100 ms, and the launch waits.  A
+// line of at least Y T bytes (delimiter dropped; Y = 8) is therefore listed as ceil(len / C) PIECES
+// of C = T bytes instead: piece j > 0 is the "line" [j C - 64, (j + 1) C) whose first block is
+// walked from the initial state only to arrive in a guess of the piece's entry state (what a
+// regex DFA is in
+// depends on the last few bytes, unless the border falls inside a long match); k_ragged walks
+// pieces like lines - they are list entries, spread over all workgroups - and leaves a record
+// per piece; k_ragged_pieces_fold then chains each line's records, re-walking a piece whose
+// guess was wrong from its true entry state (k_chunk.h does this for fixed strides).
+// Bounds: lines in pieces <= total / (Y T) <= n / (X Y); pieces <= sum(len / T + 1) over them
+// <= n / X + n / (X Y); list entries = the other long lines + pieces <= 2 n / X + n / (X Y).
+// (Cutting EVERY long line into pieces of T / 2 was measured too: it loses - 2^20 geometric lines
+// 209 against 196 us, 2^23 1024 against 933, one 1 MB line 1101 against 621 us - the lead-ins, the
+// list and the fold cost more than a 9-turn line's latency, which the other lanes' lines hide.)
 constexpr int kOutlierThreads = 256;
 constexpr uint32_t kOutlierMinBytes = 512;
+constexpr uint32_t kPieceLead = 64;           // bytes walked in front of a piece: one block
+constexpr uint64_t kEntryPiece = 1ull << 63;  // flags in the top bits of a list entry's end
+constexpr uint64_t kEntryLead = 1ull << 62;
+
+struct OutlierBufs {
+  uint32_t *ctl;     // [0] entries, [1] T, [2] lines in pieces, [3] pieces, [4] C (8 words)
+  uint32_t *outLn;   // [capE] line index, or the piece's index
+  uint64_t *outRec;  // [capE][2] first byte walked, end (+ trailing bytes to drop) | flags
+  uint32_t *hugeLn, *hugeFirst;  // [capH]
+  uint32_t capE, capH, capP;
+};
 
 __global__ void __launch_bounds__(kOutlierThreads)
 k_ragged_outliers(const uint8_t *data, const uint64_t *offsets, uint64_t nMax, const uint64_t *nDev,
-                  uint32_t factor, uint32_t cap, uint8_t *pad, uint32_t *ctl, uint32_t *outLn,
-                  uint64_t *outRec) {
-  __shared__ uint32_t cnt, base, fill;
+                  uint32_t factor, uint32_t trim, uint32_t hugeX, uint8_t *pad, OutlierBufs ob) {
+  __shared__ uint32_t cnt[3], base[3], fill[3];  // entries, huge lines, pieces
   const uint64_t n = raggedLineCount(nMax, nDev);
   const uint64_t total = offsets[n];
   if (blockIdx.x == 0 && threadIdx.x < 192) {
@@ -838,13 +896,20 @@ k_ragged_outliers(const uint8_t *data, const uint64_t *offsets, uint64_t nMax, c
   }
   uint64_t T = n ? (total + n - 1) / n * factor : 0xffffffffull;
   if (T < kOutlierMinBytes) T = kOutlierMinBytes;
+  T = (T + 63) & ~63ull;  // pieces are whole blocks
   if (T >= 0xffffffffull) T = 0xffffffffull;  // "no line is long" to k_ragged
-  if (blockIdx.x == 0 && threadIdx.x == 0) ctl[1] = uint32_t(T);
+  const uint64_t C = T;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { ob.ctl[1] = uint32_t(T); ob.ctl[4] = uint32_t(C); }
   if (T == 0xffffffffull) return;
-  if (threadIdx.x == 0) { cnt = 0; fill = 0; }
+  if (threadIdx.x < 3) { cnt[threadIdx.x] = 0; fill[threadIdx.x] = 0; }
   __syncthreads();
   const uint64_t lo = n * blockIdx.x / gridDim.x, hi = n * (blockIdx.x + 1) / gridDim.x;
-  uint32_t mine = 0;
+  // pieces of a long line: 0 = it stays whole
+  auto piecesOf = [&](uint64_t raw) -> uint32_t {
+    const uint64_t eff = raw >= trim ? raw - trim : 0;
+    return hugeX && eff >= hugeX * T ? uint32_t((eff + C - 1) / C) : 0u;
+  };
+  uint32_t mine[3] = {0, 0, 0};
   // (four independent pairs of requests per trip: one pair per trip ran at 1.2 TB/s)
   for (uint64_t i = lo + threadIdx.x; i < hi; i += 4 * kOutlierThreads) {
     uint64_t a[4], b[4];
@@ -855,22 +920,160 @@ k_ragged_outliers(const uint8_t *data, const uint64_t *offsets, uint64_t nMax, c
       b[k] = offsets[at < hi ? at + 1 : lo];
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) mine += b[k] - a[k] >= T ? 1u : 0u;
+    for (int k = 0; k < 4; ++k) {
+      if (b[k] - a[k] < T) continue;
+      const uint32_t p = piecesOf(b[k] - a[k]);
+      mine[0] += p ? p : 1u;
+      mine[1] += p ? 1u : 0u;
+      mine[2] += p;
+    }
   }
-  for (int o = 32; o; o >>= 1) mine += __shfl_xor(mine, o);
-  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&cnt, mine);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    for (int o = 32; o; o >>= 1) mine[q] += __shfl_xor(mine[q], o);
+    if ((threadIdx.x & 63) == 0 && mine[q]) atomicAdd(&cnt[q], mine[q]);
+  }
   __syncthreads();
-  if (cnt == 0) return;
-  if (threadIdx.x == 0) base = atomicAdd(&ctl[0], cnt);
+  if (cnt[0] == 0) return;
+  if (threadIdx.x == 0) base[0] = atomicAdd(&ob.ctl[0], cnt[0]);
+  if (threadIdx.x == 1 && cnt[1]) base[1] = atomicAdd(&ob.ctl[2], cnt[1]);
+  if (threadIdx.x == 2 && cnt[2]) base[2] = atomicAdd(&ob.ctl[3], cnt[2]);
   __syncthreads();
   for (uint64_t i = lo + threadIdx.x; i < hi; i += kOutlierThreads) {
     const uint64_t o = offsets[i], e = offsets[i + 1];
     if (e - o < T) continue;
-    const uint32_t k = base + atomicAdd(&fill, 1u);
-    if (k >= cap) continue;  // (cannot happen: see the bound above)
-    outLn[k] = uint32_t(i);
-    outRec[2 * uint64_t(k)] = o;
-    outRec[2 * uint64_t(k) + 1] = e;
+    const uint32_t p = piecesOf(e - o);
+    if (!p) {
+      const uint32_t k = base[0] + atomicAdd(&fill[0], 1u);
+      if (k >= ob.capE) continue;  // (cannot happen: see the bounds above)
+      ob.outLn[k] = uint32_t(i);
+      ob.outRec[2 * uint64_t(k)] = o;
+      ob.outRec[2 * uint64_t(k) + 1] = e;
+      continue;
+    }
+    const uint32_t k = base[0] + atomicAdd(&fill[0], p);
+    const uint32_t h = base[1] + atomicAdd(&fill[1], 1u);
+    const uint32_t first = base[2] + atomicAdd(&fill[2], p);
+    if (uint64_t(k) + p > ob.capE || h >= ob.capH || uint64_t(first) + p > ob.capP) continue;
+    ob.hugeLn[h] = uint32_t(i);
+    ob.hugeFirst[h] = first;
+    const uint64_t end = e - trim;  // (p != 0: the line is longer than its trailing bytes)
+    for (uint32_t j = 0; j < p; ++j) {
+      const uint64_t from = o + uint64_t(j) * C;
+      const uint64_t to = from + C < end ? from + C : end;
+      ob.outLn[k + j] = first + j;
+      ob.outRec[2 * uint64_t(k + j)] = j ? from - kPieceLead : from;
+      ob.outRec[2 * uint64_t(k + j) + 1] = (to + trim) | kEntryPiece | (j ? kEntryLead : 0ull);
+    }
+  }
+}
+
+// One WAVE per line in pieces.  A piece that was entered in the state its predecessor left stands as
+// recorded; if that holds for every piece of the line (64 at a time: a megabyte is 1800 pieces,
+// and a lane that chained them one dependent load after the other took 0.4 ms) the Outcome comes
+// from the last piece with an accept, the last with a "left the initial state" and the last
+// piece's exit state.  Otherwise lane 0 chains the records in order and walks a piece whose guess
+// was wrong again from its true entry state (the table comes to LDS only if some line of the
+// workgroup needs that).  The Outcome is what k_ragged reports for a whole line: the last accept
+// (Last) or the final state (Full), the last "left the initial state".
+constexpr int kFoldThreads = 256;
+constexpr int kFoldLines = kFoldThreads / 64;  // per workgroup and trip
+
+__global__ void __launch_bounds__(kFoldThreads)
+k_ragged_pieces_fold(DevDfa d, Batch io, int acc, int wantStart) {
+  extern __shared__ __align__(16) uint8_t foldTab[];
+  const uint32_t nHuge = io.outCtl[2];
+  if (nHuge == 0) return;
+  const uint64_t C = io.outCtl[4];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  bool staged = false;
+  for (uint32_t h0 = blockIdx.x * kFoldLines; h0 < nHuge; h0 += gridDim.x * kFoldLines) {
+    const uint32_t h = h0 + wave;
+    const bool valid = h < nHuge;
+    const uint32_t ln = valid ? io.hugeLn[h] : 0u;
+    const uint32_t first = valid ? io.hugeFirst[h] : 0u;
+    const uint64_t o = io.offsets[ln];
+    const uint64_t raw = io.offsets[ln + 1] - o;
+    const uint64_t eff = raw >= io.stride ? raw - io.stride : 0;
+    const uint32_t P = valid ? uint32_t((eff + C - 1) / C) : 0u;
+    // positions in a piece's record count from its first walked byte
+    auto walkedFrom = [&](uint32_t jj) -> uint64_t { return jj ? uint64_t(jj) * C - kPieceLead : 0; };
+    auto entOf = [](int32_t rec) { return (uint32_t(rec) >> 8) & 0xffu; };
+    auto exitOf = [](int32_t rec) { return (uint32_t(rec) >> 16) & 0xffu; };
+    bool bad = false;
+    uint32_t lastAcc = 0, lastStart = 0;  // 1 + piece
+    for (uint32_t j = lane; j < P; j += 64) {
+      const int32_t rec = io.pieceRes[first + j];
+      const uint32_t before = j ? exitOf(io.pieceRes[first + j - 1]) : d.init;
+      bad = bad || entOf(rec) != before;
+      if ((rec >> 24) & 1) lastAcc = j + 1;
+      if (wantStart && io.pieceStart[first + j]) lastStart = j + 1;
+    }
+    const bool anyBad = __builtin_amdgcn_ballot_w64(bad) != 0;
+    for (int o2 = 32; o2; o2 >>= 1) {
+      const uint32_t a = __shfl_xor(lastAcc, o2), b2 = __shfl_xor(lastStart, o2);
+      lastAcc = a > lastAcc ? a : lastAcc;
+      lastStart = b2 > lastStart ? b2 : lastStart;
+    }
+    uint32_t entry = d.init, accState = 0;
+    bool accepted = false;
+    uint64_t en = 0, st = 0;
+    if (!anyBad && P) {
+      if (lastAcc) {
+        accepted = true;
+        accState = uint32_t(io.pieceRes[first + lastAcc - 1]) & 0xffu;
+        en = walkedFrom(lastAcc - 1) + io.pieceEnd[first + lastAcc - 1];
+      }
+      if (lastStart) st = walkedFrom(lastStart - 1) + io.pieceStart[first + lastStart - 1];
+      entry = exitOf(io.pieceRes[first + P - 1]);
+    }
+    if (__syncthreads_or(anyBad ? 1 : 0)) {
+      if (!staged) {
+        for (uint32_t i = threadIdx.x; i < d.tableBytes / 16; i += kFoldThreads)
+          reinterpret_cast<uint4 *>(foldTab)[i] = reinterpret_cast<const uint4 *>(d.table)[i];
+        staged = true;
+        __syncthreads();
+      }
+      if (anyBad && lane == 0) {
+        for (uint32_t j = 0; j < P; ++j) {
+          const int32_t rec = io.pieceRes[first + j];
+          if (entOf(rec) == entry) {
+            if ((rec >> 24) & 1) {
+              accepted = true;
+              accState = uint32_t(rec) & 0xffu;
+              en = walkedFrom(j) + io.pieceEnd[first + j];
+            }
+            if (wantStart) {
+              const uint64_t sv = io.pieceStart[first + j];
+              if (sv) st = walkedFrom(j) + sv;
+            }
+            entry = exitOf(rec);
+            continue;
+          }
+          const uint64_t from = uint64_t(j) * C;
+          const uint64_t to = from + C < eff ? from + C : eff;
+          uint32_t s = entry;
+          for (uint64_t i = from; i < to; ++i) {
+            const uint32_t was = s;
+            s = foldTab[(s << 8) | io.data[o + i]];
+            if (was == d.init && s != was) st = i;
+            if (s >= d.firstAccept) { accepted = true; accState = s; en = i + 1; }
+          }
+          entry = s;
+        }
+      }
+    }
+    if (!valid || lane != 0) continue;
+    int32_t rr;
+    if (acc) {
+      rr = accepted ? d.result[accState] : 0;
+    } else {
+      rr = entry >= d.firstAccept ? d.result[entry] : 0;
+      en = eff;
+    }
+    io.result[ln] = rr;
+    if (io.end) io.end[ln] = rr ? en : 0;
+    if (wantStart && io.start) io.start[ln] = rr ? st : 0;
   }
 }
 
@@ -895,32 +1098,57 @@ hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
   const uint64_t blocks = tiles < uint64_t(cfg.numCUs) ? tiles : uint64_t(cfg.numCUs);
   Batch rb = b;
   // lines are handed out in input order, the long ones of a large batch first
-  // (REDGPU_F_NO_BUCKETING: plain input order).  Scratch: [pad 256][ctl 16][outLn u32[cap]]
-  // [outRec u64[2 cap]]
+  // (REDGPU_F_NO_BUCKETING: plain input order), the huge ones of a forgetful DFA in pieces.
+  // Scratch: [pad 256][ctl 32][outLn u32[capE]][outRec u64[2 capE]][hugeLn, hugeFirst u32[capH]]
+  // [pieceRes i32[capP]][pieceEnd, pieceStart u64[capP]], every part 16-byte aligned.
   const uint32_t factor = raggedLongFactor();
   const bool longFirst = factor && !cfg.noBucketing && b.n >= kBucketMinLines;
-  const uint64_t cap = longFirst ? b.n / factor + 64 : 0;
-  const size_t lnBytes = (size_t(cap) * 4 + 15) & ~size_t(15);
+  static const bool piecesOn = [] { const char *e = getenv("REDGPU_RAGGED_PIECES"); return !e || atoi(e) != 0; }();
+  const bool pieces = longFirst && piecesOn && TABK == kTabFused && d.forgetful;
+  const uint64_t perX = longFirst ? (b.n + factor - 1) / factor : 0;
+  auto pad16 = [](size_t v) { return (v + 15) & ~size_t(15); };
+  static const uint32_t hugeX = [] {
+    const char *e = getenv("REDGPU_RAGGED_HUGE_X");  // lab: pieces from hugeX x T bytes on
+    const int v = e ? atoi(e) : 8;
+    return uint32_t(v < 2 ? 2 : v > 1024 ? 1024 : v);
+  }();
+  const uint64_t capH = pieces ? perX / hugeX + 64 : 0;
+  const uint64_t capP = pieces ? perX + perX / hugeX + 64 : 0;
+  const uint64_t capE = longFirst ? perX + capP + 64 : 0;
+  const size_t offLn = 256 + 32, offRec = offLn + pad16(capE * 4), offHuge = offRec + capE * 16;
+  const size_t offPRes = offHuge + 2 * pad16(capH * 4), offPEnd = offPRes + pad16(capP * 4);
+  const size_t bytes = offPEnd + 2 * capP * 8;
+  if (capE >= (1ull << 32)) return hipErrorInvalidValue;  // (n < 2^32: cannot happen)
   void *scratch = nullptr;
-  hipError_t e = raggedScratch(stream, 256 + 16 + lnBytes + size_t(cap) * 16, &scratch);
+  hipError_t e = raggedScratch(stream, bytes, &scratch);
   if (e != hipSuccess) return e;
   uint8_t *pad = static_cast<uint8_t *>(scratch);
   rb.pad = pad;
   rb.outLn = reinterpret_cast<const uint32_t *>(pad);
   if (longFirst) {
-    uint32_t *ctl = reinterpret_cast<uint32_t *>(pad + 256);
-    uint32_t *outLn = reinterpret_cast<uint32_t *>(pad + 256 + 16);
-    uint64_t *outRec = reinterpret_cast<uint64_t *>(pad + 256 + 16 + lnBytes);
-    e = hipMemsetAsync(ctl, 0, 16, stream);
+    OutlierBufs ob;
+    ob.ctl = reinterpret_cast<uint32_t *>(pad + 256);
+    ob.outLn = reinterpret_cast<uint32_t *>(pad + offLn);
+    ob.outRec = reinterpret_cast<uint64_t *>(pad + offRec);
+    ob.hugeLn = reinterpret_cast<uint32_t *>(pad + offHuge);
+    ob.hugeFirst = reinterpret_cast<uint32_t *>(pad + offHuge + pad16(capH * 4));
+    ob.capE = uint32_t(capE); ob.capH = uint32_t(capH); ob.capP = uint32_t(capP);
+    e = hipMemsetAsync(ob.ctl, 0, 32, stream);
     if (e != hipSuccess) return e;
     const uint64_t want = (b.n + 4095) / 4096;
     const uint32_t nb = uint32_t(want < 2ull * uint64_t(cfg.numCUs) ? want : 2ull * uint64_t(cfg.numCUs));
     hipLaunchKernelGGL(k_ragged_outliers, dim3(nb), dim3(kOutlierThreads), 0, stream, b.data,
-                       b.offsets, b.n, b.nDev, factor, uint32_t(cap), pad, ctl, outLn, outRec);
-    rb.outCtl = ctl;
-    rb.outLn = outLn;
-    rb.outRec = outRec;
-
+                       b.offsets, b.n, b.nDev, factor, uint32_t(b.stride), pieces ? hugeX : 0u, pad, ob);
+    rb.outCtl = ob.ctl;
+    rb.outLn = ob.outLn;
+    rb.outRec = ob.outRec;
+    if (pieces) {
+      rb.hugeLn = ob.hugeLn;
+      rb.hugeFirst = ob.hugeFirst;
+      rb.pieceRes = reinterpret_cast<int32_t *>(pad + offPRes);
+      rb.pieceEnd = reinterpret_cast<uint64_t *>(pad + offPEnd);
+      rb.pieceStart = rb.pieceEnd + capP;
+    }
   } else {
     hipLaunchKernelGGL(k_tail_pad, dim3(1), dim3(192), 0, stream, b.data, b.offsets, b.n, pad,
                        b.nDev);
@@ -929,5 +1157,14 @@ hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((k_ragged<MODE, TABK>), dim3(uint32_t(blocks)), dim3(kStreamThreads), 0,
                      stream, d, rb);
+  e = hipGetLastError();
+  if (e != hipSuccess || !pieces) return e;
+  constexpr bool kAcc = MODE == kSmLastStartEnd || MODE == kSmLastEnd;
+  constexpr bool kStart = MODE == kSmLastStartEnd || MODE == kSmFullStart;
+  // (dynamic LDS = the fused table, at most 64 KB: no attribute to raise)
+  const uint64_t foldWant = (capH + kFoldLines - 1) / kFoldLines;
+  const uint32_t foldBlocks = uint32_t(foldWant < 2ull * uint64_t(cfg.numCUs) ? foldWant : 2ull * uint64_t(cfg.numCUs));
+  hipLaunchKernelGGL(k_ragged_pieces_fold, dim3(foldBlocks), dim3(kFoldThreads), d.tableBytes, stream, d, rb,
+                     kAcc ? 1 : 0, kStart ? 1 : 0);
   return hipGetLastError();
 }

@@ -65,6 +65,14 @@ struct Batch {
   const uint64_t *outRec = nullptr; // [nOut][2] = the line's offsets[] pair
   const uint32_t *outLn = nullptr;  // [nOut] = its index
   const uint32_t *outCtl = nullptr; // [0] = nOut, [1] = the length from which a line is one
+  // ... and the lines of at least twice that length, cut into pieces that are walked at once
+  // (k_ragged.h "pieces"; fused-u8 tables of DFAs that forget their past): records per piece,
+  // folded into the lines' Outcomes by k_ragged_pieces_fold
+  int32_t *pieceRes = nullptr;      // [nPieces] last accepting state | entry << 8 | exit << 16 | accepted << 24
+  uint64_t *pieceEnd = nullptr;     // [nPieces] end of that accept, from the piece's first walked byte
+  uint64_t *pieceStart = nullptr;   // [nPieces] last "left the initial state", likewise
+  uint32_t *hugeLn = nullptr;       // [nHuge] the line, [nHuge] its first piece (outCtl[2] = nHuge)
+  uint32_t *hugeFirst = nullptr;
   // k_ragged family only (launchBatch answers hipErrorNotSupported for the others): the line
   // count is still on the device - min(*nDev, n) lines, n = what the arrays have room for
   // (redgpu_*_text_dev: the count comes from the line split queued just before)

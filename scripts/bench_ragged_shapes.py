@@ -17,7 +17,9 @@ cases = [("all 256 B", np.full(n, 256)), ("all 250 B", np.full(n, 250)), ("all 6
          ("uniform 193-256", rng.integers(193, 257, n)), ("half 64 half 256", np.where(rng.integers(0, 2, n) == 1, 64, 256)),
          ("X-A 64*r(1..4)", 64 * rng.integers(1, 5, n)), ("X-B 64*r(0..3)+37", 64 * rng.integers(0, 4, n) + 37),
          ("X-C 16*r(2..16)", 16 * rng.integers(2, 17, n)), ("X-D 64*r(0..3)+r(1..64)", 64 * rng.integers(0, 4, n) + rng.integers(1, 65, n)),
-         ("X-E 64*r(0..3)+4*r(1..16)", 64 * rng.integers(0, 4, n) + 4 * rng.integers(1, 17, n))]
+         ("X-E 64*r(0..3)+4*r(1..16)", 64 * rng.integers(0, 4, n) + 4 * rng.integers(1, 17, n)),
+         ("one 1 MB line among 32-256", np.concatenate([rng.integers(32, 257, n - 1), [1 << 20]])),
+         ("a 64 KB line per 4096", np.where(np.arange(n) % 4096 == 7, 65536, rng.integers(32, 257, n)))]
 only = os.environ.get("CASES")
 for label, lens in cases:
     if only and not any(k in label for k in only.split(",")): continue

@@ -1442,6 +1442,67 @@ def test_ragged_long_lines_first(name):
             assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee)
 
 
+@pytest.mark.parametrize("name", ["uri", "newyork", "dotstar_err", "uri_user", "syn256"])
+def test_ragged_huge_lines_in_pieces(name):
+    """k_ragged's pieces: a line of >= 8 T bytes (T = max(512, 4 x mean), batches of >= 16384
+    lines, fused-u8 table, a DFA flagged `forgetful`) is walked as ceil(len / T) pieces at once,
+    each entered through a 64-byte lead-in from the initial state; k_ragged_pieces_fold chains the
+    records and re-walks pieces whose guess was wrong.  The text is dense with matches, among them
+    URLs of ~300 bytes, so that piece borders fall INSIDE matches (wrong guesses, accepts that
+    end exactly on a border, records that start in one piece and end in another); lines of 1 KB
+    to 600 KB among short ones; delimiter-terminated lines (stride = 1); all of it against the
+    oracle and against the same handle with REDGPU_F_NO_BUCKETING (whole lines, no list)."""
+    blob = load_dfa(name)
+    cpu = O.CpuOracle(blob)
+    exe = one_amd.Executable(blob)
+    exe_plain = one_amd.Executable(blob, no_bucketing=True)
+    rng = np.random.default_rng(41)
+    n = 18000
+    lens = rng.integers(0, 90, n).astype(np.int64)
+    where = rng.choice(n, 60, replace=False)
+    lens[where] = rng.integers(1024, 50000, 60)
+    lens[where[:8]] = [1024, 1025, 1087, 1088, 1089, 1536, 600000, 2048]
+    # T = max(512, 4 x mean) in whole blocks; pieces from 8 T on: lengths on both sides of that
+    for _ in range(3):
+        t = (max(512, 4 * -(-int(lens.sum()) // n)) + 63) // 64 * 64
+        lens[where[8:28]] = 8 * t + np.arange(-10, 10)
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    total = int(offsets[-1])
+    data = (W.random_bytes if name == "syn256" else W.alphabet_bytes)(total, 43).copy()
+    if name != "syn256":
+        short = np.frombuffer(W.URI_PLANT + b" New York error ", dtype=np.uint8)
+        long_url = np.frombuffer(b" https://www.example.org/" + b"seg-ment_1.2/" * 22 + b"?q=1 New ", dtype=np.uint8)
+        for at in range(0, total - 400, 211):
+            data[at:at + len(short)] = short
+        for at in range(97, total - 400, 1777):
+            data[at:at + len(long_url)] = long_url
+    info = exe.info
+    for si in (4, 5):
+        er, es, ee = cpu.batch("match", si, 0, data, offsets=offsets, threads=4)
+        for ex in (exe, exe_plain):
+            r, s, e = one_amd.match_batch(ex, data, si, 0, offsets=offsets)
+            assert one_amd.last_kernel().startswith("k_ragged"), one_amd.last_kernel()
+            bad = np.nonzero((r != er) | (s != es) | (e != ee))[0]
+            assert bad.size == 0, (name, si, bad[:5], lens[bad[:5]], r[bad[:5]], er[bad[:5]],
+                                   s[bad[:5]], es[bad[:5]], e[bad[:5]], ee[bad[:5]], info["forgetful"])
+            r2, _, e2 = one_amd.match_batch(ex, data, si, 0, offsets=offsets, want_start=False)
+            assert np.array_equal(r2, er) and np.array_equal(e2, ee)
+        assert np.array_equal(one_amd.check_batch(exe, data, si, 0, offsets=offsets),
+                              cpu.batch("check", si, 0, data, offsets=offsets, threads=4)[0])
+    if name != "syn256":
+        last = cpu.batch("match", 4, 0, data, offsets=offsets, threads=4)[0].astype(bool)
+        assert int(last.sum()) > 1000 and last[where].sum() > 50   # the text does match, huge lines too
+    # delimiter-terminated lines: the pieces are cut from the line without its trailing byte
+    keep = np.ones(total, dtype=bool)
+    keep[(offsets[1:][lens > 0] - np.uint64(1)).astype(np.int64)] = False
+    coffs = np.zeros(n + 1, dtype=np.uint64)
+    coffs[1:] = np.cumsum(np.maximum(lens - 1, 0))
+    er, es, ee = cpu.batch("match", 4, 0, data[keep], offsets=coffs, threads=4)
+    r, s, e = one_amd.match_batch(exe, data, 4, 0, offsets=offsets, stride=1)
+    assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee)
+
+
 def test_match_all_on_gpu():
     """matchAll batch form (include/Matcher.h:711-766) vs the reference's known answers
     (test/matcher.cpp:695-745, every format) and the reference outputs in

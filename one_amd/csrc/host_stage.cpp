@@ -3,6 +3,7 @@
 #include "host_stage.h"
 
 #include <atomic>
+#include <cstring>
 #include <memory>
 #include <vector>
 
@@ -152,7 +153,70 @@ hipError_t HostStage::sync() {
     hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) return e;
   }
+  flush(-1);
+  bounceUsed_ = 0;  // nothing of the arena is in flight any more, either way
   return hipSuccess;
+}
+
+hipError_t HostStage::syncStream(int idx) {
+  hipError_t e = hipStreamSynchronize(streams[idx]);
+  if (e != hipSuccess) return e;
+  flush(idx);
+  return hipSuccess;
+}
+
+void HostStage::flush(int idx) {
+  size_t keep = 0;
+  for (size_t i = 0; i < pending_.size(); ++i) {
+    const Pending &p = pending_[i];
+    if (idx < 0 || p.idx == idx) memcpy(p.dst, p.src, p.bytes);
+    else pending_[keep++] = p;
+  }
+  pending_.resize(keep);
+}
+
+// `bytes` of the pinned arena (64-byte aligned), or nullptr when the transfer should go direct.
+// A full arena waits for what is in flight and starts over; one that is too small is replaced
+// (only ever with nothing in flight).
+void *HostStage::bounceTake(size_t bytes) {
+  const size_t need = (bytes + 63) & ~size_t(63);
+  if (bounceUsed_ + need > bounceCap_) {
+    if (bounceUsed_ && sync() != hipSuccess) return nullptr;  // (sync() empties the arena)
+    bounceUsed_ = 0;
+    if (need > bounceCap_) {
+      if (bounce_) (void)hipHostFree(bounce_);
+      bounce_ = nullptr;
+      bounceCap_ = 0;
+      size_t want = need + need / 2;
+      if (want < (size_t(1) << 20)) want = size_t(1) << 20;
+      if (hipHostMalloc(&bounce_, want, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        bounce_ = nullptr;
+        return nullptr;
+      }
+      bounceCap_ = want;
+    }
+  }
+  void *p = static_cast<uint8_t *>(bounce_) + bounceUsed_;
+  bounceUsed_ += need;
+  return p;
+}
+
+hipError_t HostStage::copyIn(void *dDst, const void *hSrc, size_t bytes, int idx, bool direct) {
+  if (bytes == 0) return hipSuccess;
+  void *p = !direct && bytes <= kBounceMax ? bounceTake(bytes) : nullptr;
+  if (!p) return hipMemcpyAsync(dDst, hSrc, bytes, hipMemcpyHostToDevice, streams[idx]);
+  memcpy(p, hSrc, bytes);
+  return hipMemcpyAsync(dDst, p, bytes, hipMemcpyHostToDevice, streams[idx]);
+}
+
+hipError_t HostStage::copyOut(void *hDst, const void *dSrc, size_t bytes, int idx, bool direct) {
+  if (bytes == 0) return hipSuccess;
+  void *p = !direct && bytes <= kBounceMax ? bounceTake(bytes) : nullptr;
+  if (!p) return hipMemcpyAsync(hDst, dSrc, bytes, hipMemcpyDeviceToHost, streams[idx]);
+  hipError_t e = hipMemcpyAsync(p, dSrc, bytes, hipMemcpyDeviceToHost, streams[idx]);
+  if (e == hipSuccess) pending_.push_back(Pending{hDst, p, bytes, idx});
+  return e;
 }
 
 void HostStage::release() {
@@ -166,6 +230,10 @@ void HostStage::release() {
     b.p = nullptr;
     b.cap = 0;
   }
+  if (bounce_) (void)hipHostFree(bounce_);
+  bounce_ = nullptr;
+  bounceCap_ = bounceUsed_ = 0;
+  pending_.clear();
   for (hipStream_t &s : streams) {
     if (s) {
       scratchDrop(device, s);

@@ -12,6 +12,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <vector>
 
 #include <hip/hip_runtime.h>
 
@@ -27,11 +28,39 @@ class HostStage {
   // grow-only device buffer `slot` of at least `bytes` (+16: 16-byte loads of a last line never
   // leave the allocation).  Growing waits for this thread's own streams, then frees and allocates.
   hipError_t get(int slot, size_t bytes, void **out);
-  hipError_t sync();  // both streams
+  hipError_t sync();  // both streams; completes the copyOut()s behind them
   void release();
   ~HostStage() { release(); }
 
+  // Caller memory <-> device, asynchronously on streams[idx].  Pageable caller memory of up to
+  // kBounceMax bytes per transfer goes through this thread's own PINNED arena (a CPU copy in
+  // front of the upload / behind the download): handed to hipMemcpyAsync as it is, pageable
+  // memory above ~1 MiB is pinned by the runtime on the fly and the pinning cached by address -
+  // when the caller's allocator has meanwhile returned part of that range to the system (a
+  // heap that shrank) the next copy over the cached pin faults on the GPU (seen in round 3 as
+  // an intermittent "Memory access fault" at a host heap address in the test suite, whose numpy
+  // buffers come and go).  Larger transfers and memory the caller pinned go direct.
+  // copyOut()'s bytes are in the caller's buffer after syncStream(idx) / sync().
+  static constexpr size_t kBounceMax = size_t(16) << 20;
+  hipError_t copyIn(void *dDst, const void *hSrc, size_t bytes, int idx, bool direct = false);
+  hipError_t copyOut(void *hDst, const void *dSrc, size_t bytes, int idx, bool direct = false);
+  hipError_t syncStream(int idx);
+  // at the top of a host-buffer entry point (the one before left with its streams drained)
+  void beginCall() { if (pending_.empty()) bounceUsed_ = 0; }
+
  private:
+  void *bounceTake(size_t bytes);
+  void flush(int idx);  // the finished downloads of stream idx (-1: all) into the caller's buffers
+  void *bounce_ = nullptr;
+  size_t bounceCap_ = 0, bounceUsed_ = 0;
+  struct Pending {
+    void *dst;
+    const void *src;
+    size_t bytes;
+    int idx;
+  };
+  std::vector<Pending> pending_;
+
   struct Buf {
     void *p = nullptr;
     size_t cap = 0;

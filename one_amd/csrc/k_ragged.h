@@ -1077,6 +1077,12 @@ k_ragged_pieces_fold(DevDfa d, Batch io, int acc, int wantStart) {
   }
 }
 
+// the smallest batch whose long lines are listed.  The list costs a small batch 5-6 us (1024 to
+// 16384 lines of 32-256 B: 34 -> 40 us per launch) and is what keeps ONE huge line from holding
+// it for milliseconds (the same batches with a 1 MB line: 67.5 ms -> 0.17-0.36 ms;
+// scripts/lab/run_small.sh).
+constexpr uint64_t kLongFirstMinLines = 1024;
+
 // X of the rule above; REDGPU_RAGGED_LONG_X overrides it (lab; 0 = no list, >= 2 otherwise)
 inline uint32_t raggedLongFactor() {
   static const uint32_t x = [] {
@@ -1102,7 +1108,12 @@ hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
   // Scratch: [pad 256][ctl 32][outLn u32[capE]][outRec u64[2 capE]][hugeLn, hugeFirst u32[capH]]
   // [pieceRes i32[capP]][pieceEnd, pieceStart u64[capP]], every part 16-byte aligned.
   const uint32_t factor = raggedLongFactor();
-  const bool longFirst = factor && !cfg.noBucketing && b.n >= kBucketMinLines;
+  static const uint64_t minLines = [] {
+    const char *e = getenv("REDGPU_RAGGED_LONG_MIN");  // lab: smallest batch that gets the list
+    const long v = e ? atol(e) : long(kLongFirstMinLines);
+    return uint64_t(v < 64 ? 64 : v);
+  }();
+  const bool longFirst = factor && !cfg.noBucketing && b.n >= minLines;
   static const bool piecesOn = [] { const char *e = getenv("REDGPU_RAGGED_PIECES"); return !e || atoi(e) != 0; }();
   const bool pieces = longFirst && piecesOn && TABK == kTabFused && d.forgetful;
   const uint64_t perX = longFirst ? (b.n + factor - 1) / factor : 0;

@@ -204,6 +204,7 @@ int runHost(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   HostStage *st = nullptr;
   if (int rc = stageOf(dfa, &st)) return rc;
+  st->beginCall();
 
   // Caller memory that is already pinned (redgpu_host_register, hipHostMalloc, torch's
   // pin_memory): its copies are asynchronous as they stand, so even a batch of a few MiB is worth
@@ -271,12 +272,14 @@ int runHost(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint
   // pinned caller memory makes the copies truly asynchronous (only worth its price when there
   // is something to overlap)
   const bool pinNow = multi && !callerPinned;
+  // several chunks: the caller's memory is pinned (by the caller, or for this call just below)
+  // and copied as it is; one chunk of pageable memory goes through the thread's pinned arena
+  const bool direct = multi || callerPinned;
   ScopedPin pinIn(data, total, pinNow), pinRes(result, n * 4, pinNow),
       pinStart(start, start ? n * 8 : 0, pinNow), pinEnd(end, end ? n * 8 : 0, pinNow);
 
   if (offsets) {
-    STAGE_TRY(hipMemcpyAsync(dOff, offsets, (n + 1) * 8, hipMemcpyHostToDevice, st->streams[0]),
-              "copy offsets");
+    STAGE_TRY(st->copyIn(dOff, offsets, (n + 1) * 8, 0, direct), "copy offsets");
     if (multi) {
       STAGE_TRY(hipEventRecord(st->ready, st->streams[0]), "hipEventRecord");
       STAGE_TRY(hipStreamWaitEvent(st->streams[1], st->ready, 0), "hipStreamWaitEvent");
@@ -289,7 +292,7 @@ int runHost(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint
     const uint64_t byteLo = offsets ? offsets[lo] : lo * stride;
     const uint64_t bytes = offsets ? offsets[hi] - byteLo : nl * stride;
     if (bytes)
-      STAGE_TRY(hipMemcpyAsync(dData[k], data + byteLo, bytes, hipMemcpyHostToDevice, s), "copy data");
+      STAGE_TRY(st->copyIn(dData[k], data + byteLo, bytes, k, direct), "copy data");
     const uint64_t *chunkOff = offsets ? dOff + lo : nullptr;
     if (offsets && byteLo) {
       const uint32_t blocks = uint32_t((nl + 256) / 256 < 1024 ? (nl + 256) / 256 : 1024);
@@ -303,11 +306,9 @@ int runHost(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint
       (void)st->sync();
       return rc;
     }
-    STAGE_TRY(hipMemcpyAsync(result + lo, dRes[k], nl * 4, hipMemcpyDeviceToHost, s), "copy result");
-    if (start)
-      STAGE_TRY(hipMemcpyAsync(start + lo, dStart[k], nl * 8, hipMemcpyDeviceToHost, s), "copy start");
-    if (end)
-      STAGE_TRY(hipMemcpyAsync(end + lo, dEnd[k], nl * 8, hipMemcpyDeviceToHost, s), "copy end");
+    STAGE_TRY(st->copyOut(result + lo, dRes[k], nl * 4, k, direct), "copy result");
+    if (start) STAGE_TRY(st->copyOut(start + lo, dStart[k], nl * 8, k, direct), "copy start");
+    if (end) STAGE_TRY(st->copyOut(end + lo, dEnd[k], nl * 8, k, direct), "copy end");
   }
   STAGE_TRY(st->sync(), "hipStreamSynchronize");
   return REDGPU_OK;
@@ -649,6 +650,7 @@ static int listHost(const redgpu_dfa *dfa, int listVerb, const uint8_t *data,
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   HostStage *st = nullptr;
   if (int rc = stageOf(dfa, &st)) return rc;
+  st->beginCall();
   hipStream_t s = st->streams[0];
   uint8_t *dData = nullptr;
   uint64_t *dOff = nullptr, *dCnt = nullptr, *dStart = nullptr, *dEnd = nullptr;
@@ -663,21 +665,21 @@ static int listHost(const redgpu_dfa *dfa, int listVerb, const uint8_t *data,
     STAGE_TRY(st->get(kSlEnd, (slots + 1) * 8, reinterpret_cast<void **>(&dEnd)), "hipMalloc end");
   if (offsets) {
     STAGE_TRY(st->get(kSlOff, (n + 1) * 8, reinterpret_cast<void **>(&dOff)), "hipMalloc offsets");
-    STAGE_TRY(hipMemcpyAsync(dOff, offsets, (n + 1) * 8, hipMemcpyHostToDevice, s), "copy offsets");
+    STAGE_TRY(st->copyIn(dOff, offsets, (n + 1) * 8, 0), "copy offsets");
   }
-  if (total) STAGE_TRY(hipMemcpyAsync(dData, data, total, hipMemcpyHostToDevice, s), "copy data");
+  if (total) STAGE_TRY(st->copyIn(dData, data, total, 0), "copy data");
   const int rc = collectDev(dfa, listVerb, dData, dOff, stride, n, cap, dCnt, dRes, dStart, dEnd, s);
   if (rc != REDGPU_OK) {
     (void)st->sync();
     return rc;
   }
-  STAGE_TRY(hipMemcpyAsync(counts, dCnt, n * 8, hipMemcpyDeviceToHost, s), "copy counts");
+  STAGE_TRY(st->copyOut(counts, dCnt, n * 8, 0), "copy counts");
   if (slots) {
-    STAGE_TRY(hipMemcpyAsync(result, dRes, slots * 4, hipMemcpyDeviceToHost, s), "copy result");
-    if (start) STAGE_TRY(hipMemcpyAsync(start, dStart, slots * 8, hipMemcpyDeviceToHost, s), "copy start");
-    if (end) STAGE_TRY(hipMemcpyAsync(end, dEnd, slots * 8, hipMemcpyDeviceToHost, s), "copy end");
+    STAGE_TRY(st->copyOut(result, dRes, slots * 4, 0), "copy result");
+    if (start) STAGE_TRY(st->copyOut(start, dStart, slots * 8, 0), "copy start");
+    if (end) STAGE_TRY(st->copyOut(end, dEnd, slots * 8, 0), "copy end");
   }
-  STAGE_TRY(hipStreamSynchronize(s), "hipStreamSynchronize");
+  STAGE_TRY(st->syncStream(0), "hipStreamSynchronize");
   return REDGPU_OK;
 }
 
@@ -726,6 +728,7 @@ int redgpu_replace_batch(const redgpu_dfa *dfa, int style, int do_leader, const 
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   HostStage *st = nullptr;
   if (int rc = stageOf(dfa, &st)) return rc;
+  st->beginCall();
   hipStream_t s = st->streams[0];
   uint8_t *dData = nullptr, *dRepl = nullptr, *dOut = nullptr;
   uint64_t *dOff = nullptr, *dCnt = nullptr, *dOutOff = nullptr;
@@ -737,10 +740,10 @@ int redgpu_replace_batch(const redgpu_dfa *dfa, int style, int do_leader, const 
     STAGE_TRY(st->get(kSlAux3, out_cap, reinterpret_cast<void **>(&dOut)), "hipMalloc out");
   if (offsets) {
     STAGE_TRY(st->get(kSlOff, (n + 1) * 8, reinterpret_cast<void **>(&dOff)), "hipMalloc offsets");
-    STAGE_TRY(hipMemcpyAsync(dOff, offsets, (n + 1) * 8, hipMemcpyHostToDevice, s), "copy offsets");
+    STAGE_TRY(st->copyIn(dOff, offsets, (n + 1) * 8, 0), "copy offsets");
   }
-  if (total) STAGE_TRY(hipMemcpyAsync(dData, data, total, hipMemcpyHostToDevice, s), "copy data");
-  if (repl_len) STAGE_TRY(hipMemcpyAsync(dRepl, repl, repl_len, hipMemcpyHostToDevice, s), "copy repl");
+  if (total) STAGE_TRY(st->copyIn(dData, data, total, 0), "copy data");
+  if (repl_len) STAGE_TRY(st->copyIn(dRepl, repl, repl_len, 0), "copy repl");
   const int rc = redgpu_replace_batch_dev(dfa, style, do_leader, dData, dOff, stride, n, dRepl,
                                           repl_len, max_count, dCnt, dOutOff, dOut,
                                           dOut ? out_cap : 0, s);
@@ -748,10 +751,10 @@ int redgpu_replace_batch(const redgpu_dfa *dfa, int style, int do_leader, const 
     (void)st->sync();
     return rc;
   }
-  STAGE_TRY(hipMemcpyAsync(counts, dCnt, n * 8, hipMemcpyDeviceToHost, s), "copy counts");
-  STAGE_TRY(hipMemcpyAsync(out_offsets, dOutOff, (n + 1) * 8, hipMemcpyDeviceToHost, s),
+  STAGE_TRY(st->copyOut(counts, dCnt, n * 8, 0), "copy counts");
+  STAGE_TRY(st->copyOut(out_offsets, dOutOff, (n + 1) * 8, 0),
             "copy out offsets");
-  STAGE_TRY(hipStreamSynchronize(s), "hipStreamSynchronize");
+  STAGE_TRY(st->syncStream(0), "hipStreamSynchronize");
   if (dOut) {
     // the lines that fit are a prefix (offsets are monotone): copy up to the last one that does
     uint64_t lo = 0, hi = n;  // largest k with out_offsets[k] <= out_cap
@@ -760,8 +763,8 @@ int redgpu_replace_batch(const redgpu_dfa *dfa, int style, int do_leader, const 
       if (out_offsets[mid] <= out_cap) lo = mid; else hi = mid - 1;
     }
     if (out_offsets[lo]) {
-      STAGE_TRY(hipMemcpyAsync(out, dOut, out_offsets[lo], hipMemcpyDeviceToHost, s), "copy out");
-      STAGE_TRY(hipStreamSynchronize(s), "hipStreamSynchronize");
+      STAGE_TRY(st->copyOut(out, dOut, out_offsets[lo], 0), "copy out");
+      STAGE_TRY(st->syncStream(0), "hipStreamSynchronize");
     }
   }
   return REDGPU_OK;
@@ -779,19 +782,20 @@ int redgpu_split_lines_dev(const redgpu_dfa *dfa, const uint8_t *data, uint64_t 
   hipStream_t s = static_cast<hipStream_t>(stream);
   const uint64_t nChunks = splitChunks(len);
   void *scratch = nullptr;
-  // counts u32[nChunks], bases u64[nChunks], then the delimiter masks (2 bytes per 16 of input);
-  // stream-ordered so the call stays asynchronous
+  // counts u32[nChunks], bases u64[nChunks], then the delimiter masks (2 bytes per 16 of input):
+  // the calling thread's scratch for this stream (kernels.h) - what the next launch on the
+  // stream does with the same buffer comes behind these kernels.  (Up to round 3 this was
+  // hipMallocAsync / hipFreeAsync per call: ~12 us of host time each, and the only use of the
+  // stream-ordered allocator in the library.)
   const size_t countBytes = (size_t(nChunks) * 4 + 15) & ~size_t(15);
   const size_t headBytes = countBytes + size_t(nChunks) * 8 + 16;
-  HIP_TRY(hipMallocAsync(&scratch, headBytes + splitMaskBytes(len), s), "hipMallocAsync");
+  HIP_TRY(scratchFor(s, headBytes + splitMaskBytes(len) + 16, &scratch), "hipMalloc scratch");
   uint32_t *counts = static_cast<uint32_t *>(scratch);
   uint64_t *bases = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(scratch) + countBytes);
   uint16_t *masks = reinterpret_cast<uint16_t *>(static_cast<uint8_t *>(scratch) + headBytes);
   hipError_t e = launchSplitLines(data, len, delim, offsets, cap, n_lines, counts, bases, masks, s);
   tlsKernel = "k_split_scatter";
-  hipError_t e2 = hipFreeAsync(scratch, s);
   if (e != hipSuccess) return failHip(e, "kernel launch");
-  if (e2 != hipSuccess) return failHip(e2, "hipFreeAsync");
   return REDGPU_OK;
 }
 
@@ -855,6 +859,7 @@ int redgpu_match_text(const redgpu_dfa *dfa, int style, int do_leader, const uin
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   HostStage *st = nullptr;
   if (int rc = stageOf(dfa, &st)) return rc;
+  st->beginCall();
   hipStream_t s = st->streams[0];
   if (cap > len) cap = len;
   uint8_t *dData = nullptr;
@@ -866,23 +871,23 @@ int redgpu_match_text(const redgpu_dfa *dfa, int style, int do_leader, const uin
   STAGE_TRY(st->get(kSlRes, cap * 4, reinterpret_cast<void **>(&dRes)), "hipMalloc result");
   if (start) STAGE_TRY(st->get(kSlStart, cap * 8, reinterpret_cast<void **>(&dStart)), "hipMalloc start");
   if (end) STAGE_TRY(st->get(kSlEnd, cap * 8, reinterpret_cast<void **>(&dEnd)), "hipMalloc end");
-  if (len) STAGE_TRY(hipMemcpyAsync(dData, data, len, hipMemcpyHostToDevice, s), "copy data");
+  if (len) STAGE_TRY(st->copyIn(dData, data, len, 0), "copy data");
   const int rc = textDev(dfa, start || end ? kMatch : kCheck, style, do_leader, dData, len, delim,
                          dOff, cap, dN, dRes, dStart, dEnd, s);
   if (rc != REDGPU_OK) {
     (void)st->sync();
     return rc;
   }
-  STAGE_TRY(hipMemcpyAsync(n_lines, dN, 8, hipMemcpyDeviceToHost, s), "copy count");
-  STAGE_TRY(hipStreamSynchronize(s), "hipStreamSynchronize");
+  STAGE_TRY(st->copyOut(n_lines, dN, 8, 0), "copy count");
+  STAGE_TRY(st->syncStream(0), "hipStreamSynchronize");
   const uint64_t got = *n_lines < cap ? *n_lines : cap;
-  if (cap) STAGE_TRY(hipMemcpyAsync(offsets, dOff, (got + 1) * 8, hipMemcpyDeviceToHost, s), "copy offsets");
+  if (cap) STAGE_TRY(st->copyOut(offsets, dOff, (got + 1) * 8, 0), "copy offsets");
   if (got) {
-    STAGE_TRY(hipMemcpyAsync(result, dRes, got * 4, hipMemcpyDeviceToHost, s), "copy result");
-    if (start) STAGE_TRY(hipMemcpyAsync(start, dStart, got * 8, hipMemcpyDeviceToHost, s), "copy start");
-    if (end) STAGE_TRY(hipMemcpyAsync(end, dEnd, got * 8, hipMemcpyDeviceToHost, s), "copy end");
+    STAGE_TRY(st->copyOut(result, dRes, got * 4, 0), "copy result");
+    if (start) STAGE_TRY(st->copyOut(start, dStart, got * 8, 0), "copy start");
+    if (end) STAGE_TRY(st->copyOut(end, dEnd, got * 8, 0), "copy end");
   }
-  STAGE_TRY(hipStreamSynchronize(s), "hipStreamSynchronize");
+  STAGE_TRY(st->syncStream(0), "hipStreamSynchronize");
   return REDGPU_OK;
 }
 
@@ -896,6 +901,7 @@ int redgpu_split_lines(const redgpu_dfa *dfa, const uint8_t *data, uint64_t len,
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   HostStage *st = nullptr;
   if (int rc = stageOf(dfa, &st)) return rc;
+  st->beginCall();
   hipStream_t s = st->streams[0];
   uint8_t *dData = nullptr;
   uint64_t *dOff = nullptr, *dN = nullptr;
@@ -903,14 +909,14 @@ int redgpu_split_lines(const redgpu_dfa *dfa, const uint8_t *data, uint64_t len,
   STAGE_TRY(st->get(kSlAux0, 8, reinterpret_cast<void **>(&dN)), "hipMalloc count");
   // count first (room for no line at all), then size the device offsets to what will be kept
   STAGE_TRY(st->get(kSlOff, 8, reinterpret_cast<void **>(&dOff)), "hipMalloc offsets");
-  if (len) STAGE_TRY(hipMemcpyAsync(dData, data, len, hipMemcpyHostToDevice, s), "copy data");
+  if (len) STAGE_TRY(st->copyIn(dData, data, len, 0), "copy data");
   int rc = redgpu_split_lines_dev(dfa, dData, len, delim, dOff, 0, dN, s);
   if (rc != REDGPU_OK) {
     (void)st->sync();
     return rc;
   }
-  STAGE_TRY(hipMemcpyAsync(n_lines, dN, 8, hipMemcpyDeviceToHost, s), "copy count");
-  STAGE_TRY(hipStreamSynchronize(s), "hipStreamSynchronize");
+  STAGE_TRY(st->copyOut(n_lines, dN, 8, 0), "copy count");
+  STAGE_TRY(st->syncStream(0), "hipStreamSynchronize");
   const uint64_t got = *n_lines < cap ? *n_lines : cap;
   if (got) {
     STAGE_TRY(st->get(kSlOff, (got + 1) * 8, reinterpret_cast<void **>(&dOff)), "hipMalloc offsets");
@@ -920,8 +926,8 @@ int redgpu_split_lines(const redgpu_dfa *dfa, const uint8_t *data, uint64_t len,
       return rc;
     }
   }
-  STAGE_TRY(hipMemcpyAsync(offsets, dOff, (got + 1) * 8, hipMemcpyDeviceToHost, s), "copy offsets");
-  STAGE_TRY(hipStreamSynchronize(s), "hipStreamSynchronize");
+  STAGE_TRY(st->copyOut(offsets, dOff, (got + 1) * 8, 0), "copy offsets");
+  STAGE_TRY(st->syncStream(0), "hipStreamSynchronize");
   return REDGPU_OK;
 }
 
@@ -1092,15 +1098,16 @@ int redgpu_dfa_tune(redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offset
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   HostStage *st = nullptr;
   if (int rc = stageOf(dfa, &st)) return rc;
+  st->beginCall();
   hipStream_t s = st->streams[0];
   uint8_t *dData = nullptr;
   uint64_t *dOff = nullptr;
   STAGE_TRY(st->get(kSlData, total, reinterpret_cast<void **>(&dData)), "hipMalloc data");
   if (offsets) {
     STAGE_TRY(st->get(kSlOff, (n + 1) * 8, reinterpret_cast<void **>(&dOff)), "hipMalloc offsets");
-    STAGE_TRY(hipMemcpyAsync(dOff, offsets, (n + 1) * 8, hipMemcpyHostToDevice, s), "copy offsets");
+    STAGE_TRY(st->copyIn(dOff, offsets, (n + 1) * 8, 0), "copy offsets");
   }
-  if (total) STAGE_TRY(hipMemcpyAsync(dData, data, total, hipMemcpyHostToDevice, s), "copy data");
+  if (total) STAGE_TRY(st->copyIn(dData, data, total, 0), "copy data");
   return redgpu_dfa_tune_dev(dfa, dData, dOff, stride, n, s);  // synchronises
 }
 
@@ -1139,6 +1146,7 @@ int redgpu_advance_batch(const redgpu_dfa *dfa, const uint8_t *data, const uint6
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   HostStage *st = nullptr;
   if (int rc = stageOf(dfa, &st)) return rc;
+  st->beginCall();
   hipStream_t s = st->streams[0];
   uint8_t *dData = nullptr;
   uint64_t *dOff = nullptr;
@@ -1149,18 +1157,18 @@ int redgpu_advance_batch(const redgpu_dfa *dfa, const uint8_t *data, const uint6
   STAGE_TRY(st->get(kSlRes, n * 4, reinterpret_cast<void **>(&dRes)), "hipMalloc result");
   if (offsets) {
     STAGE_TRY(st->get(kSlOff, (n + 1) * 8, reinterpret_cast<void **>(&dOff)), "hipMalloc offsets");
-    STAGE_TRY(hipMemcpyAsync(dOff, offsets, (n + 1) * 8, hipMemcpyHostToDevice, s), "copy offsets");
+    STAGE_TRY(st->copyIn(dOff, offsets, (n + 1) * 8, 0), "copy offsets");
   }
-  if (total) STAGE_TRY(hipMemcpyAsync(dData, data, total, hipMemcpyHostToDevice, s), "copy data");
-  STAGE_TRY(hipMemcpyAsync(dState, state, n * 4, hipMemcpyHostToDevice, s), "copy state");
+  if (total) STAGE_TRY(st->copyIn(dData, data, total, 0), "copy data");
+  STAGE_TRY(st->copyIn(dState, state, n * 4, 0), "copy state");
   const int rc = redgpu_advance_batch_dev(dfa, dData, dOff, stride, n, dState, dRes, s);
   if (rc != REDGPU_OK) {
     (void)st->sync();
     return rc;
   }
-  STAGE_TRY(hipMemcpyAsync(state, dState, n * 4, hipMemcpyDeviceToHost, s), "copy state back");
-  STAGE_TRY(hipMemcpyAsync(result, dRes, n * 4, hipMemcpyDeviceToHost, s), "copy result");
-  STAGE_TRY(hipStreamSynchronize(s), "hipStreamSynchronize");
+  STAGE_TRY(st->copyOut(state, dState, n * 4, 0), "copy state back");
+  STAGE_TRY(st->copyOut(result, dRes, n * 4, 0), "copy result");
+  STAGE_TRY(st->syncStream(0), "hipStreamSynchronize");
   return REDGPU_OK;
 }
 

@@ -10,6 +10,7 @@ host arrays (numpy / bytes -> the library stages them) or torch tensors resident
 from __future__ import annotations
 
 import ctypes as C
+import os
 import enum
 
 import numpy as np
@@ -178,6 +179,9 @@ def _host_u8(data) -> np.ndarray:
     return a
 
 
+_TRACE = bool(os.environ.get("REDGPU_PY_TRACE"))  # debugging aid: host buffer addresses per call
+
+
 def _run(verb: str, exe: Executable, style, do_leader, data, offsets, stride, n, want_start,
          want_end, out=None):
     """Returns (result, start, end); start/end are None when not requested / not a match verb."""
@@ -233,6 +237,11 @@ def _run(verb: str, exe: Executable, style, do_leader, data, offsets, stride, n,
     en = np.zeros(n, dtype=np.uint64) if want_end else None
     op = offsets.ctypes.data if offsets is not None else None
     dp = a.ctypes.data if a.size else None
+    if _TRACE:
+        print("redgpu host call %s n=%d data=%#x+%d offsets=%s res=%#x start=%s end=%s" % (
+            verb, n, dp or 0, a.size, "%#x" % op if op else None, res.ctypes.data,
+            "%#x" % st.ctypes.data if st is not None else None,
+            "%#x" % en.ctypes.data if en is not None else None), flush=True)
     if verb in ("match", "search"):
         fhost = l.redgpu_match_batch if verb == "match" else l.redgpu_search_batch
         rc = fhost(exe._h, style, lead, dp, op, stride, n, res.ctypes.data,

@@ -65,6 +65,13 @@ int main(int argc, char **argv) {
     std::vector<Outcome> tx = matchText(rex, "New\nnothing here\nI love New York.\n\nNew York", styLast,
                                         true, '\n', &starts);
     EXPECT_EQ(size_t(4), tx.size());
+    if (tx.size() == 4 && tx[0].result_ != 1) {  // what came back, for the log
+      std::fprintf(stderr, "matchText: results");
+      for (const Outcome &o : tx) std::fprintf(stderr, " (%d %zu %zu)", o.result_, o.start_, o.end_);
+      std::fprintf(stderr, " starts");
+      for (size_t v : starts) std::fprintf(stderr, " %zu", v);
+      std::fprintf(stderr, " kernel %s\n", redgpu_last_kernel());
+    }
     EXPECT_EQ(1, tx[0].result_);
     EXPECT_EQ(0, tx[1].result_);
     EXPECT_EQ(2, tx[2].result_);

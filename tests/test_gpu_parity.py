@@ -887,7 +887,7 @@ def test_match_text_one_call(name):
     (tools/skim_red.cpp:36-46) in one call, against oracle.split_lines + CpuOracle on the lines
     with their delimiters removed.  Buffers: empty; one delimiter; runs of empty lines; no
     trailing delimiter; nothing but delimiters; no delimiter at all; a line far longer than the
-    rest; > 16384 lines (the long-lines list of k_ragged is in play).  cap below the number of
+    rest; > 1024 lines (the long-lines list of k_ragged is in play).  cap below the number of
     lines keeps the first cap and still reports the count.  DFAs: the k_ragged family reads the
     line count on the device (uri, syn256, uri_v6 hot rows); log100 / err (die early: k_early,
     k_generic) and newyork4 take the count through the host."""
@@ -1384,7 +1384,7 @@ def test_ragged_stream_kernel_tail_and_shapes(name):
 
 @pytest.mark.parametrize("name", ["syn256", "uri", "uri_v6"])
 def test_ragged_long_lines_first(name):
-    """k_ragged with k_ragged_outliers' list (batches of >= 16384 lines): lines of at least
+    """k_ragged with k_ragged_outliers' list (batches of >= 1024 lines): lines of at least
     max(512, 4 x mean) bytes are walked first, out of input order, and passed over in the
     workgroup's contiguous range.  Shapes: geometric lengths; a RUN of long lines (every lane of a
     wave finds its current and its next line passed over); long lines at the very start / end; one
@@ -1444,7 +1444,7 @@ def test_ragged_long_lines_first(name):
 
 @pytest.mark.parametrize("name", ["uri", "newyork", "dotstar_err", "uri_user", "syn256"])
 def test_ragged_huge_lines_in_pieces(name):
-    """k_ragged's pieces: a line of >= 8 T bytes (T = max(512, 4 x mean), batches of >= 16384
+    """k_ragged's pieces: a line of >= 8 T bytes (T = max(512, 4 x mean), batches of >= 1024
     lines, fused-u8 table, a DFA flagged `forgetful`) is walked as ceil(len / T) pieces at once,
     each entered through a 64-byte lead-in from the initial state; k_ragged_pieces_fold chains the
     records and re-walks pieces whose guess was wrong.  The text is dense with matches, among them

@@ -204,7 +204,7 @@ void *HostStage::bounceTake(size_t bytes) {
 
 hipError_t HostStage::copyIn(void *dDst, const void *hSrc, size_t bytes, int idx, bool direct) {
   if (bytes == 0) return hipSuccess;
-  void *p = !direct && bytes <= kBounceMax ? bounceTake(bytes) : nullptr;
+  void *p = !direct && !callDirect_ && bytes <= kBounceMax ? bounceTake(bytes) : nullptr;
   if (!p) return hipMemcpyAsync(dDst, hSrc, bytes, hipMemcpyHostToDevice, streams[idx]);
   memcpy(p, hSrc, bytes);
   return hipMemcpyAsync(dDst, p, bytes, hipMemcpyHostToDevice, streams[idx]);
@@ -212,7 +212,7 @@ hipError_t HostStage::copyIn(void *dDst, const void *hSrc, size_t bytes, int idx
 
 hipError_t HostStage::copyOut(void *hDst, const void *dSrc, size_t bytes, int idx, bool direct) {
   if (bytes == 0) return hipSuccess;
-  void *p = !direct && bytes <= kBounceMax ? bounceTake(bytes) : nullptr;
+  void *p = !direct && !callDirect_ && bytes <= kBounceMax ? bounceTake(bytes) : nullptr;
   if (!p) return hipMemcpyAsync(hDst, dSrc, bytes, hipMemcpyDeviceToHost, streams[idx]);
   hipError_t e = hipMemcpyAsync(p, dSrc, bytes, hipMemcpyDeviceToHost, streams[idx]);
   if (e == hipSuccess) pending_.push_back(Pending{hDst, p, bytes, idx});

@@ -33,8 +33,10 @@ class HostStage {
   ~HostStage() { release(); }
 
   // Caller memory <-> device, asynchronously on streams[idx].  Pageable caller memory of up to
-  // kBounceMax bytes per transfer goes through this thread's own PINNED arena (a CPU copy in
-  // front of the upload / behind the download): handed to hipMemcpyAsync as it is, pageable
+  // kBounceMax bytes per transfer, in calls whose input is below kDirectFrom bytes, goes through
+  // this thread's own PINNED arena (a CPU copy in front of the upload / behind the download; a
+  // call of 8 MiB and more is a throughput call and keeps the runtime's own path - the copy in
+  // the middle cost 2^20 x 64-byte lines 40.9 -> 25.8 GB/s): handed to hipMemcpyAsync as it is, pageable
   // memory above ~1 MiB is pinned by the runtime on the fly and the pinning cached by address -
   // when the caller's allocator has meanwhile returned part of that range to the system (a
   // heap that shrank) the next copy over the cached pin faults on the GPU (seen in round 3 as
@@ -42,15 +44,22 @@ class HostStage {
   // buffers come and go).  Larger transfers and memory the caller pinned go direct.
   // copyOut()'s bytes are in the caller's buffer after syncStream(idx) / sync().
   static constexpr size_t kBounceMax = size_t(16) << 20;
+  static constexpr size_t kDirectFrom = size_t(8) << 20;
   hipError_t copyIn(void *dDst, const void *hSrc, size_t bytes, int idx, bool direct = false);
   hipError_t copyOut(void *hDst, const void *dSrc, size_t bytes, int idx, bool direct = false);
   hipError_t syncStream(int idx);
-  // at the top of a host-buffer entry point (the one before left with its streams drained)
-  void beginCall() { if (pending_.empty()) bounceUsed_ = 0; }
+  // at the top of a host-buffer entry point (the one before left with its streams drained);
+  // inputBytes = what the call uploads
+  void beginCall(size_t inputBytes) {
+    if (pending_.empty()) bounceUsed_ = 0;
+    callDirect_ = inputBytes >= kDirectFrom;
+  }
+  bool callDirect() const { return callDirect_; }
 
  private:
   void *bounceTake(size_t bytes);
   void flush(int idx);  // the finished downloads of stream idx (-1: all) into the caller's buffers
+  bool callDirect_ = false;
   void *bounce_ = nullptr;
   size_t bounceCap_ = 0, bounceUsed_ = 0;
   struct Pending {

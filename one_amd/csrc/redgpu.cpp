@@ -204,7 +204,7 @@ int runHost(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   HostStage *st = nullptr;
   if (int rc = stageOf(dfa, &st)) return rc;
-  st->beginCall();
+  st->beginCall(total);
 
   // Caller memory that is already pinned (redgpu_host_register, hipHostMalloc, torch's
   // pin_memory): its copies are asynchronous as they stand, so even a batch of a few MiB is worth
@@ -273,8 +273,8 @@ int runHost(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint
   // is something to overlap)
   const bool pinNow = multi && !callerPinned;
   // several chunks: the caller's memory is pinned (by the caller, or for this call just below)
-  // and copied as it is; one chunk of pageable memory goes through the thread's pinned arena
-  const bool direct = multi || callerPinned;
+  // and copied as it is; a small call's pageable memory goes through the thread's pinned arena
+  const bool direct = multi || callerPinned || st->callDirect();
   ScopedPin pinIn(data, total, pinNow), pinRes(result, n * 4, pinNow),
       pinStart(start, start ? n * 8 : 0, pinNow), pinEnd(end, end ? n * 8 : 0, pinNow);
 
@@ -650,7 +650,7 @@ static int listHost(const redgpu_dfa *dfa, int listVerb, const uint8_t *data,
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   HostStage *st = nullptr;
   if (int rc = stageOf(dfa, &st)) return rc;
-  st->beginCall();
+  st->beginCall(total);
   hipStream_t s = st->streams[0];
   uint8_t *dData = nullptr;
   uint64_t *dOff = nullptr, *dCnt = nullptr, *dStart = nullptr, *dEnd = nullptr;
@@ -728,7 +728,7 @@ int redgpu_replace_batch(const redgpu_dfa *dfa, int style, int do_leader, const 
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   HostStage *st = nullptr;
   if (int rc = stageOf(dfa, &st)) return rc;
-  st->beginCall();
+  st->beginCall(total);
   hipStream_t s = st->streams[0];
   uint8_t *dData = nullptr, *dRepl = nullptr, *dOut = nullptr;
   uint64_t *dOff = nullptr, *dCnt = nullptr, *dOutOff = nullptr;
@@ -859,7 +859,7 @@ int redgpu_match_text(const redgpu_dfa *dfa, int style, int do_leader, const uin
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   HostStage *st = nullptr;
   if (int rc = stageOf(dfa, &st)) return rc;
-  st->beginCall();
+  st->beginCall(len);
   hipStream_t s = st->streams[0];
   if (cap > len) cap = len;
   uint8_t *dData = nullptr;
@@ -901,7 +901,7 @@ int redgpu_split_lines(const redgpu_dfa *dfa, const uint8_t *data, uint64_t len,
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   HostStage *st = nullptr;
   if (int rc = stageOf(dfa, &st)) return rc;
-  st->beginCall();
+  st->beginCall(len);
   hipStream_t s = st->streams[0];
   uint8_t *dData = nullptr;
   uint64_t *dOff = nullptr, *dN = nullptr;
@@ -1098,7 +1098,7 @@ int redgpu_dfa_tune(redgpu_dfa *dfa, const uint8_t *data, const uint64_t *offset
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   HostStage *st = nullptr;
   if (int rc = stageOf(dfa, &st)) return rc;
-  st->beginCall();
+  st->beginCall(total);
   hipStream_t s = st->streams[0];
   uint8_t *dData = nullptr;
   uint64_t *dOff = nullptr;
@@ -1146,7 +1146,7 @@ int redgpu_advance_batch(const redgpu_dfa *dfa, const uint8_t *data, const uint6
   if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
   HostStage *st = nullptr;
   if (int rc = stageOf(dfa, &st)) return rc;
-  st->beginCall();
+  st->beginCall(total);
   hipStream_t s = st->streams[0];
   uint8_t *dData = nullptr;
   uint64_t *dOff = nullptr;

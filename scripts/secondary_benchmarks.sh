@@ -14,6 +14,7 @@ run bench_anchored.py
 run bench_longlines.py syn4k
 run bench_ragged_shapes.py
 LINES=8388608 run bench_ragged_shapes.py
+CASES="geometric,uniform 32-256,one 1 MB,a 64 KB" run bench_ragged_shapes.py uri
 run prof_ragged.py uri
 run prof_ragged.py uri generic
 run prof_ragged.py uri_user

@@ -260,8 +260,10 @@ int redgpu_replace_batch(const redgpu_dfa *dfa, int style, int do_leader, const 
 /* ---- the same verbs over DEVICE-resident buffers, asynchronous on `stream` ---------------
  * data/offsets/result/start/end are device pointers on the handle's device; `stream` is a
  * hipStream_t (NULL = the default stream).  Nothing is copied or synchronised; the only
- * allocation is the scratch some launches need (the ragged kernels' tail pad and length buckets,
- * the chunked walk's records, replace's partial sums): kept per HOST THREAD and (device, stream)
+ * allocation is the scratch some launches need (the ragged kernels' tail pad, their list of long
+ * lines and the records of huge lines walked in pieces - up to ~16 bytes per line of the batch -,
+ * the chunked walk's records, replace's partial sums, line splitting's delimiter masks - 1/8 of
+ * the text): kept per HOST THREAD and (device, stream)
  * and re-used by that thread's later calls on the stream - so any number of threads may issue
  * _dev calls on one stream, the default one included - (re)allocated, with a device
  * synchronisation, only when a call needs more than the cached buffer holds; freed when the

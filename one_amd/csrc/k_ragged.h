@@ -1173,8 +1173,9 @@ hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
   constexpr bool kAcc = MODE == kSmLastStartEnd || MODE == kSmLastEnd;
   constexpr bool kStart = MODE == kSmLastStartEnd || MODE == kSmFullStart;
   // (dynamic LDS = the fused table, at most 64 KB: no attribute to raise)
-  // (a small grid: a batch without huge lines pays this launch for nothing - 512 workgroups that
-  // leave at once took 4.7 us - and one with them has a few per million lines)
+  // (a small grid: a batch has a few huge lines per million at most.  One without any pays this
+  // launch for nothing: 4-5 us by the rocprofv3 trace whatever the grid - the dispatch with its
+  // 54 KB of LDS and one dependent load of the count.)
   const uint64_t foldWant = (capH + kFoldLines - 1) / kFoldLines;
   const uint32_t foldBlocks = uint32_t(foldWant < 64 ? foldWant : 64);
   hipLaunchKernelGGL(k_ragged_pieces_fold, dim3(foldBlocks), dim3(kFoldThreads), d.tableBytes, stream, d, rb,

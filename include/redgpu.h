@@ -418,6 +418,11 @@ int redgpu_diag_walked_dev(const redgpu_dfa *dfa, int do_leader, const uint8_t *
  * (bounded per thread; diagnostics / tests). */
 void redgpu_thread_release(void);
 uint64_t redgpu_scratch_entries(void);
+/* Diagnostics: how the host-buffer entry points have moved caller memory so far, transfers by
+ * route - [0] memory the caller pinned, [1] through the calling thread's pinned arena (calls that
+ * upload < 8 MiB), [2] registered for the duration of the call, [3] handed to the runtime
+ * pageable (nothing else was possible). */
+void redgpu_host_route_counts(uint64_t counts[4]);
 
 /* A caller that keeps its buffers from call to call (tools/thr_red.cpp's workers do) can pin them
  * ONCE: the host-buffer entry points recognise pinned memory (registered here, or allocated by

@@ -169,6 +169,8 @@ def lib() -> C.CDLL:
         l.redgpu_host_unregister.argtypes = [vp]
         l.redgpu_thread_release.restype = None
         l.redgpu_scratch_entries.restype = u64
+        l.redgpu_host_route_counts.restype = None
+        l.redgpu_host_route_counts.argtypes = [vp]
         l.redgpu_group_create.restype = C.c_int
         l.redgpu_group_create.argtypes = [vp, C.c_size_t, C.POINTER(Opts), C.POINTER(C.c_int32),
                                           C.c_uint32, C.POINTER(vp)]

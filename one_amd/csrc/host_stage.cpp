@@ -173,6 +173,32 @@ void HostStage::flush(int idx) {
     else pending_[keep++] = p;
   }
   pending_.resize(keep);
+  keep = 0;
+  for (size_t i = 0; i < tempPins_.size(); ++i) {
+    if (idx < 0 || tempPins_[i].idx == idx) (void)hipHostUnregister(tempPins_[i].p);
+    else tempPins_[keep++] = tempPins_[i];
+  }
+  tempPins_.resize(keep);
+}
+
+// is p host memory the runtime knows as pinned (hipHostMalloc / hipHostRegister)?
+bool isPinnedHost(const void *p) {
+  if (!p) return false;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // plain pageable memory: not an error of the call
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
+bool HostStage::pinForCall(const void *p, size_t bytes, int idx) {
+  if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  tempPins_.push_back(TempPin{const_cast<void *>(p), idx});
+  return true;
 }
 
 // `bytes` of the pinned arena (64-byte aligned), or nullptr when the transfer should go direct.
@@ -202,9 +228,27 @@ void *HostStage::bounceTake(size_t bytes) {
   return p;
 }
 
+// how a transfer of caller memory goes: 0 = as it is (pinned, or nothing else is possible),
+// otherwise through `*slice` of the arena
+std::atomic<uint64_t> gRoute[4];  // transfers: caller-pinned, through the arena, registered, pageable
+
+void *HostStage::routeOf(const void *host, size_t bytes, int idx, bool direct) {
+  if (direct || isPinnedHost(host)) { ++gRoute[0]; return nullptr; }
+  void *p = nullptr;
+  if (!callDirect_ && bytes <= kBounceMax && (p = bounceTake(bytes))) { ++gRoute[1]; return p; }
+  if (pinForCall(host, bytes, idx)) { ++gRoute[2]; return nullptr; }
+  if (bytes <= kBounceMax && (p = bounceTake(bytes))) { ++gRoute[1]; return p; }
+  ++gRoute[3];
+  return nullptr;  // pageable, as a last resort
+}
+
+void hostRouteCounts(uint64_t out[4]) {
+  for (int i = 0; i < 4; ++i) out[i] = gRoute[i].load();
+}
+
 hipError_t HostStage::copyIn(void *dDst, const void *hSrc, size_t bytes, int idx, bool direct) {
   if (bytes == 0) return hipSuccess;
-  void *p = !direct && !callDirect_ && bytes <= kBounceMax ? bounceTake(bytes) : nullptr;
+  void *p = routeOf(hSrc, bytes, idx, direct);
   if (!p) return hipMemcpyAsync(dDst, hSrc, bytes, hipMemcpyHostToDevice, streams[idx]);
   memcpy(p, hSrc, bytes);
   return hipMemcpyAsync(dDst, p, bytes, hipMemcpyHostToDevice, streams[idx]);
@@ -212,7 +256,7 @@ hipError_t HostStage::copyIn(void *dDst, const void *hSrc, size_t bytes, int idx
 
 hipError_t HostStage::copyOut(void *hDst, const void *dSrc, size_t bytes, int idx, bool direct) {
   if (bytes == 0) return hipSuccess;
-  void *p = !direct && !callDirect_ && bytes <= kBounceMax ? bounceTake(bytes) : nullptr;
+  void *p = routeOf(hDst, bytes, idx, direct);
   if (!p) return hipMemcpyAsync(hDst, dSrc, bytes, hipMemcpyDeviceToHost, streams[idx]);
   hipError_t e = hipMemcpyAsync(p, dSrc, bytes, hipMemcpyDeviceToHost, streams[idx]);
   if (e == hipSuccess) pending_.push_back(Pending{hDst, p, bytes, idx});
@@ -234,6 +278,8 @@ void HostStage::release() {
   bounce_ = nullptr;
   bounceCap_ = bounceUsed_ = 0;
   pending_.clear();
+  for (const TempPin &t : tempPins_) (void)hipHostUnregister(t.p);
+  tempPins_.clear();
   for (hipStream_t &s : streams) {
     if (s) {
       scratchDrop(device, s);

@@ -42,6 +42,12 @@ class HostStage {
   // heap that shrank) the next copy over the cached pin faults on the GPU (seen in round 3 as
   // an intermittent "Memory access fault" at a host heap address in the test suite, whose numpy
   // buffers come and go).  Larger transfers and memory the caller pinned go direct.
+  // A throughput call's pageable buffers are REGISTERED for the duration of the call instead
+  // (hipHostRegister now, hipHostUnregister behind the stream's next drain): the copies then run
+  // on memory the runtime knows as pinned, and its own on-the-fly path is never taken.  (Leaving
+  // the large calls on that path was tried first: the fault came back within five suite runs, in
+  // an 18 MB call.)  A range the runtime refuses to register falls back to the arena, and only
+  // what fits neither way is handed over pageable.
   // copyOut()'s bytes are in the caller's buffer after syncStream(idx) / sync().
   static constexpr size_t kBounceMax = size_t(16) << 20;
   static constexpr size_t kDirectFrom = size_t(8) << 20;
@@ -58,6 +64,13 @@ class HostStage {
 
  private:
   void *bounceTake(size_t bytes);
+  void *routeOf(const void *host, size_t bytes, int idx, bool direct);
+  bool pinForCall(const void *p, size_t bytes, int idx);
+  struct TempPin {
+    void *p;
+    int idx;
+  };
+  std::vector<TempPin> tempPins_;
   void flush(int idx);  // the finished downloads of stream idx (-1: all) into the caller's buffers
   bool callDirect_ = false;
   void *bounce_ = nullptr;
@@ -76,6 +89,12 @@ class HostStage {
   } bufs_[kBufs];
   friend hipError_t hostStage(int, HostStage **);
 };
+
+// is p host memory the runtime knows as pinned (hipHostMalloc / hipHostRegister)?
+bool isPinnedHost(const void *p);
+// transfers of caller memory so far, by route: pinned by the caller, through a pinned arena,
+// registered for the call, handed over pageable (redgpu_host_route_counts)
+void hostRouteCounts(uint64_t out[4]);
 
 // The calling thread's stage for `device` (created on first use; the device must be current).
 hipError_t hostStage(int device, HostStage **out);

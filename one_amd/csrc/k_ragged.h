@@ -407,8 +407,8 @@ k_ragged(DevDfa d, Batch io) {
   auto passedOver = [&](int c) -> bool { return !tOut[c] && tE[c] - tO[c] >= longFrom; };
   // the two top bits of a list entry's end say what it is (offsets stay far below 2^62)
   auto takeKind = [&](int c) {
-    tKind[c] = IDXD ? 0u : uint32_t(tE[c] >> 62);
-    if (!IDXD) tE[c] &= (1ull << 62) - 1;
+    tKind[c] = CLS ? 0u : uint32_t(tE[c] >> 62);
+    if (!CLS) tE[c] &= (1ull << 62) - 1;
   };
   auto lengthOf = [&](uint64_t o, uint64_t e) -> uint32_t {
     // Batch::stride doubles as "trailing delimiter bytes per line" for ragged lines
@@ -419,7 +419,7 @@ k_ragged(DevDfa d, Batch io) {
   uint32_t g[CH];  // HOT: global id of the lane's state while it is outside the hot set
   uint64_t mA[CH], mB[CH], vA[CH], vB[CH];
   auto freshLine = [&](int c) {
-    s[c] = init; accS[c] = 0; endv[c] = 0; startv[c] = 0; g[c] = kNoState; ent[c] = init;
+    s[c] = init; accS[c] = 0; endv[c] = 0; startv[c] = 0; g[c] = kNoState; ent[c] = d.init;
     if (HOT && init == 0x1ffu) { s[c] = 255u; g[c] = d.init; }
   };
 #pragma unroll
@@ -566,11 +566,16 @@ k_ragged(DevDfa d, Batch io) {
         const bool wasInit63 = (mA[c] >> lane) & 1;
         if (full && wasInit63 && s[c] != init) startv[c] = off + 63;
       }
-      // a piece's lead-in block is behind it: what it arrived in is the guess of its entry state,
-      // and nothing seen on the way belongs to the piece
-      if (!IDXD && (kind[c] & 1u) && off == 0) {
-        ent[c] = s[c];
-        accS[c] = 0; endv[c] = 0; startv[c] = 0;
+    }
+    // a piece's lead-in block is behind it: what it arrived in (as a global state id) is the guess
+    // of its entry state, and nothing seen on the way belongs to the piece
+    if (!CLS) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        if ((kind[c] & 1u) && done[c] == 0) {
+          ent[c] = HOT ? (g[c] != kNoState ? g[c] : toGlobal(s[c])) : s[c];
+          accS[c] = 0; endv[c] = 0; startv[c] = 0;
+        }
       }
     }
 
@@ -627,14 +632,18 @@ k_ragged(DevDfa d, Batch io) {
         const uint64_t at = ln[c];
         uint8_t *dummy = const_cast<uint8_t *>(io.pad) + 192;
         // a piece leaves its record where a line leaves its Outcome: the same three stores
-        const bool piece = !IDXD && (kind[c] & 2u);
-        const int32_t rec = int32_t((endv[c] ? accS[c] : 0u) | (ent[c] << 8) | (s[c] << 16) |
-                                    (endv[c] ? 1u << 24 : 0u));
+        // (record: last accepting state | accepted << 31; end | exit state << 32 | entry guess
+        // << 48, the states as global ids - at most 16 bits, the launcher sees to that; start)
+        const bool piece = !CLS && (kind[c] & 2u);
+        const uint32_t exitG = HOT ? (g[c] != kNoState ? g[c] : toGlobal(s[c])) : s[c];
+        const int32_t rec = int32_t((endv[c] ? accS[c] : 0u) | (endv[c] ? 1u << 31 : 0u));
+        const uint64_t recEnd = uint64_t(endv[c]) | (uint64_t(exitG & 0xffffu) << 32) |
+                                (uint64_t(ent[c] & 0xffffu) << 48);
         int32_t *rp = report ? (piece ? io.pieceRes : io.result) + at : reinterpret_cast<int32_t *>(dummy);
         *rp = piece ? rec : rr;
         uint64_t *endTo = piece ? io.pieceEnd : io.end;
         uint64_t *ep = report && endTo ? endTo + at : reinterpret_cast<uint64_t *>(dummy);
-        *ep = piece ? uint64_t(endv[c]) : rr ? uint64_t(en) : 0;
+        *ep = piece ? recEnd : rr ? uint64_t(en) : 0;
         if (kStart) {
           uint64_t *startTo = piece ? io.pieceStart : io.start;
           uint64_t *sp = report && startTo ? startTo + at : reinterpret_cast<uint64_t *>(dummy);
@@ -979,8 +988,11 @@ k_ragged_outliers(const uint8_t *data, const uint64_t *offsets, uint64_t nMax, c
 constexpr int kFoldThreads = 256;
 constexpr int kFoldLines = kFoldThreads / 64;  // per workgroup and trip
 
+// (hot != 0: a REDGPU_TAB_HOT_ROWS DFA - a piece is walked again through its class table in
+// global memory, d.table as u16 rows of d.nClasses entries, byte -> class in d.equivLeader; a fused
+// table is staged to LDS instead)
 __global__ void __launch_bounds__(kFoldThreads)
-k_ragged_pieces_fold(DevDfa d, Batch io, int acc, int wantStart) {
+k_ragged_pieces_fold(DevDfa d, Batch io, int acc, int wantStart, int hot) {
   extern __shared__ __align__(16) uint8_t foldTab[];
   const uint32_t nHuge = io.outCtl[2];
   if (nHuge == 0) return;
@@ -996,17 +1008,18 @@ k_ragged_pieces_fold(DevDfa d, Batch io, int acc, int wantStart) {
     const uint64_t raw = io.offsets[ln + 1] - o;
     const uint64_t eff = raw >= io.stride ? raw - io.stride : 0;
     const uint32_t P = valid ? uint32_t((eff + C - 1) / C) : 0u;
-    // positions in a piece's record count from its first walked byte
+    // a piece's record (k_ragged's report): positions count from its first walked byte
     auto walkedFrom = [&](uint32_t jj) -> uint64_t { return jj ? uint64_t(jj) * C - kPieceLead : 0; };
-    auto entOf = [](int32_t rec) { return (uint32_t(rec) >> 8) & 0xffu; };
-    auto exitOf = [](int32_t rec) { return (uint32_t(rec) >> 16) & 0xffu; };
+    auto endOf = [](uint64_t w) { return w & 0xffffffffull; };
+    auto exitOf = [](uint64_t w) { return uint32_t(w >> 32) & 0xffffu; };
+    auto entOf = [](uint64_t w) { return uint32_t(w >> 48) & 0xffffu; };
     bool bad = false;
     uint32_t lastAcc = 0, lastStart = 0;  // 1 + piece
     for (uint32_t j = lane; j < P; j += 64) {
-      const int32_t rec = io.pieceRes[first + j];
-      const uint32_t before = j ? exitOf(io.pieceRes[first + j - 1]) : d.init;
-      bad = bad || entOf(rec) != before;
-      if ((rec >> 24) & 1) lastAcc = j + 1;
+      const uint64_t w = io.pieceEnd[first + j];
+      const uint32_t before = j ? exitOf(io.pieceEnd[first + j - 1]) : d.init;
+      bad = bad || entOf(w) != before;
+      if (io.pieceRes[first + j] < 0) lastAcc = j + 1;
       if (wantStart && io.pieceStart[first + j]) lastStart = j + 1;
     }
     const bool anyBad = __builtin_amdgcn_ballot_w64(bad) != 0;
@@ -1021,33 +1034,35 @@ k_ragged_pieces_fold(DevDfa d, Batch io, int acc, int wantStart) {
     if (!anyBad && P) {
       if (lastAcc) {
         accepted = true;
-        accState = uint32_t(io.pieceRes[first + lastAcc - 1]) & 0xffu;
-        en = walkedFrom(lastAcc - 1) + io.pieceEnd[first + lastAcc - 1];
+        accState = uint32_t(io.pieceRes[first + lastAcc - 1]) & 0x7fffffffu;
+        en = walkedFrom(lastAcc - 1) + endOf(io.pieceEnd[first + lastAcc - 1]);
       }
       if (lastStart) st = walkedFrom(lastStart - 1) + io.pieceStart[first + lastStart - 1];
-      entry = exitOf(io.pieceRes[first + P - 1]);
+      entry = exitOf(io.pieceEnd[first + P - 1]);
     }
     if (__syncthreads_or(anyBad ? 1 : 0)) {
-      if (!staged) {
+      if (!staged && !hot) {
         for (uint32_t i = threadIdx.x; i < d.tableBytes / 16; i += kFoldThreads)
           reinterpret_cast<uint4 *>(foldTab)[i] = reinterpret_cast<const uint4 *>(d.table)[i];
-        staged = true;
         __syncthreads();
       }
+      staged = true;
       if (anyBad && lane == 0) {
+        const uint16_t *cls = reinterpret_cast<const uint16_t *>(d.table);
         for (uint32_t j = 0; j < P; ++j) {
-          const int32_t rec = io.pieceRes[first + j];
-          if (entOf(rec) == entry) {
-            if ((rec >> 24) & 1) {
+          const uint64_t w = io.pieceEnd[first + j];
+          if (entOf(w) == entry) {
+            const int32_t rec = io.pieceRes[first + j];
+            if (rec < 0) {
               accepted = true;
-              accState = uint32_t(rec) & 0xffu;
-              en = walkedFrom(j) + io.pieceEnd[first + j];
+              accState = uint32_t(rec) & 0x7fffffffu;
+              en = walkedFrom(j) + endOf(w);
             }
             if (wantStart) {
               const uint64_t sv = io.pieceStart[first + j];
               if (sv) st = walkedFrom(j) + sv;
             }
-            entry = exitOf(rec);
+            entry = exitOf(w);
             continue;
           }
           const uint64_t from = uint64_t(j) * C;
@@ -1055,7 +1070,9 @@ k_ragged_pieces_fold(DevDfa d, Batch io, int acc, int wantStart) {
           uint32_t s = entry;
           for (uint64_t i = from; i < to; ++i) {
             const uint32_t was = s;
-            s = foldTab[(s << 8) | io.data[o + i]];
+            const uint32_t byte = io.data[o + i];
+            s = hot ? uint32_t(cls[size_t(s) * d.nClasses + d.equivLeader[byte]])
+                    : uint32_t(foldTab[(s << 8) | byte]);
             if (was == d.init && s != was) st = i;
             if (s >= d.firstAccept) { accepted = true; accState = s; en = i + 1; }
           }
@@ -1068,7 +1085,7 @@ k_ragged_pieces_fold(DevDfa d, Batch io, int acc, int wantStart) {
     if (acc) {
       rr = accepted ? d.result[accState] : 0;
     } else {
-      rr = entry >= d.firstAccept ? d.result[entry] : 0;
+      rr = entry >= d.firstAccept && entry < d.nStates ? d.result[entry] : 0;
       en = eff;
     }
     io.result[ln] = rr;
@@ -1115,7 +1132,9 @@ hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
   }();
   const bool longFirst = factor && !cfg.noBucketing && b.n >= minLines;
   static const bool piecesOn = [] { const char *e = getenv("REDGPU_RAGGED_PIECES"); return !e || atoi(e) != 0; }();
-  const bool pieces = longFirst && piecesOn && TABK == kTabFused && d.forgetful;
+  // (records keep states as 16-bit global ids)
+  const bool pieces = longFirst && piecesOn && d.forgetful && d.nStates <= 65535 &&
+                      (TABK == kTabFused || TABK == kTabHot);
   const uint64_t perX = longFirst ? (b.n + factor - 1) / factor : 0;
   auto pad16 = [](size_t v) { return (v + 15) & ~size_t(15); };
   static const uint32_t hugeX = [] {
@@ -1178,7 +1197,8 @@ hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
   // 54 KB of LDS and one dependent load of the count.)
   const uint64_t foldWant = (capH + kFoldLines - 1) / kFoldLines;
   const uint32_t foldBlocks = uint32_t(foldWant < 64 ? foldWant : 64);
-  hipLaunchKernelGGL(k_ragged_pieces_fold, dim3(foldBlocks), dim3(kFoldThreads), d.tableBytes, stream, d, rb,
-                     kAcc ? 1 : 0, kStart ? 1 : 0);
+  hipLaunchKernelGGL(k_ragged_pieces_fold, dim3(foldBlocks), dim3(kFoldThreads),
+                     TABK == kTabHot ? 0 : d.tableBytes, stream, d, rb, kAcc ? 1 : 0, kStart ? 1 : 0,
+                     TABK == kTabHot ? 1 : 0);
   return hipGetLastError();
 }

@@ -66,10 +66,11 @@ struct Batch {
   const uint32_t *outLn = nullptr;  // [nOut] = its index
   const uint32_t *outCtl = nullptr; // [0] = nOut, [1] = the length from which a line is one
   // ... and the lines of at least twice that length, cut into pieces that are walked at once
-  // (k_ragged.h "pieces"; fused-u8 tables of DFAs that forget their past): records per piece,
-  // folded into the lines' Outcomes by k_ragged_pieces_fold
-  int32_t *pieceRes = nullptr;      // [nPieces] last accepting state | entry << 8 | exit << 16 | accepted << 24
-  uint64_t *pieceEnd = nullptr;     // [nPieces] end of that accept, from the piece's first walked byte
+  // (k_ragged.h "pieces"; fused-u8 and hot-row tables of DFAs that forget their past): records
+  // per piece, folded into the lines' Outcomes by k_ragged_pieces_fold; states as global ids
+  int32_t *pieceRes = nullptr;      // [nPieces] last accepting state | accepted << 31
+  uint64_t *pieceEnd = nullptr;     // [nPieces] end of that accept, from the piece's first walked
+                                    // byte | exit state << 32 | entry guess << 48
   uint64_t *pieceStart = nullptr;   // [nPieces] last "left the initial state", likewise
   uint32_t *hugeLn = nullptr;       // [nHuge] the line, [nHuge] its first piece (outCtl[2] = nHuge)
   uint32_t *hugeFirst = nullptr;

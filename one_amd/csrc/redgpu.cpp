@@ -157,17 +157,6 @@ static uint64_t hostChunkBytes() {
 }
 #define kHostChunkBytes hostChunkBytes()
 
-// is p host memory the runtime knows as pinned (hipHostMalloc / hipHostRegister)?
-static bool isPinnedHost(const void *p) {
-  if (!p) return false;
-  hipPointerAttribute_t a;
-  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
-    (void)hipGetLastError();  // plain pageable memory: not an error of the call
-    return false;
-  }
-  return a.type == hipMemoryTypeHost;
-}
-
 // offsets of a chunk that does not start at byte 0, rebased to the chunk's own buffer: the
 // kernels may read data[0, offsets[n]) anywhere (lanes without a line re-read block 0), so a
 // chunk is always presented as a batch of its own
@@ -272,9 +261,10 @@ int runHost(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint
   // pinned caller memory makes the copies truly asynchronous (only worth its price when there
   // is something to overlap)
   const bool pinNow = multi && !callerPinned;
-  // several chunks: the caller's memory is pinned (by the caller, or for this call just below)
-  // and copied as it is; a small call's pageable memory goes through the thread's pinned arena
-  const bool direct = multi || callerPinned || st->callDirect();
+  // the caller's memory is pinned (by the caller, or for this call just below: several chunks)
+  // and copied as it is; otherwise HostStage::copyIn / copyOut choose per transfer (a small call's
+  // pageable memory through the thread's pinned arena, a large one's registered for the call)
+  const bool direct = callerPinned;
   ScopedPin pinIn(data, total, pinNow), pinRes(result, n * 4, pinNow),
       pinStart(start, start ? n * 8 : 0, pinNow), pinEnd(end, end ? n * 8 : 0, pinNow);
 
@@ -1029,6 +1019,8 @@ int redgpu_host_unregister(void *ptr) {
 }
 
 void redgpu_thread_release(void) { hostStageReleaseThread(); }
+
+void redgpu_host_route_counts(uint64_t counts[4]) { if (counts) hostRouteCounts(counts); }
 
 uint64_t redgpu_scratch_entries(void) { return scratchEntries(); }
 

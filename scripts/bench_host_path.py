@@ -75,3 +75,7 @@ for n, L in ((1 << 20, 64), (1 << 18, 1024)):
             for d, r, s, e, m in sets:
                 for a in (d, r, s, e):
                     l.redgpu_host_unregister(a.ctypes.data)
+import ctypes as _C
+_rc = (_C.c_uint64 * 4)()
+_lib.lib().redgpu_host_route_counts(_rc)
+print("transfers by route: caller-pinned %d, pinned arena %d, registered for the call %d, pageable %d" % tuple(_rc))

@@ -1442,10 +1442,10 @@ def test_ragged_long_lines_first(name):
             assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee)
 
 
-@pytest.mark.parametrize("name", ["uri", "newyork", "dotstar_err", "uri_user", "syn256"])
+@pytest.mark.parametrize("name", ["uri", "newyork", "dotstar_err", "uri_v6", "uri_user", "syn256"])
 def test_ragged_huge_lines_in_pieces(name):
     """k_ragged's pieces: a line of >= 8 T bytes (T = max(512, 4 x mean), batches of >= 1024
-    lines, fused-u8 table, a DFA flagged `forgetful`) is walked as ceil(len / T) pieces at once,
+    lines, fused-u8 or hot-row table (uri_v6), a DFA flagged `forgetful`) is walked as ceil(len / T) pieces at once,
     each entered through a 64-byte lead-in from the initial state; k_ragged_pieces_fold chains the
     records and re-walks pieces whose guess was wrong.  The text is dense with matches, among them
     URLs of ~300 bytes, so that piece borders fall INSIDE matches (wrong guesses, accepts that

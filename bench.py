@@ -872,6 +872,14 @@ def main():
         "timed_region_library_calls_ms": (round((host_trace[1] - host_trace[0]) * 1e3, 5)
                                           if len(host_trace) == 2 else None),
     }
+    # the timed region by its own HIP events (recorded on the launch stream in front of the first
+    # and behind the last of the K steps): the same bytes over that time.  `achieved` / `frac`
+    # above stay on kernel_ms - many launches back to back, later in the run, at sustained clocks.
+    if region_ms > 0:
+        a_tr = (walked if walked is not None else wl.in_bytes) * args.steps / (region_ms * 1e-3) / 1e9
+        roofline["timed_region"] = {"ms": round(region_ms, 5), "achieved": round(a_tr, 1),
+                                    "frac": round(a_tr / peak, 4),
+                                    "how": "HIP events around the %d timed steps" % args.steps}
     if batches_per_launch > 1:
         # the same workload one batch per launch (redgpu_match_batch_dev per step): what a caller
         # that cannot hand over several batches at once gets

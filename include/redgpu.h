@@ -88,6 +88,10 @@ typedef struct redgpu_opts {
                                      / -3 % (SYN-256), 512-byte lines -8 % - so it is opt-in */
 #define REDGPU_F_LEAN_CHAINS_4 2048u /* ... with four lines per lane (two chain groups, counted
                                      waits) instead of two */
+#define REDGPU_F_FORCE_PIECES 4096u /* ragged lines: huge lines are walked in pieces (k_ragged.h) even
+                                     when the DFA is not flagged `forgetful` - the entry-state
+                                     guesses are then mostly wrong and the pieces walked again
+                                     one by one: correct, slow (tests) */
 #define REDGPU_F_FORCE_HOT     4u /* a table too big for LDS always gets hot rows in LDS, even
                                      when the visit model finds no locality (tests, tuning) */
 

@@ -16,6 +16,7 @@ DEVICE_CURRENT, DEVICE_NONE = -1, -2
 F_FORCE_GENERIC, F_FORCE_GLOBAL, F_FORCE_HOT, F_NO_BUCKETING, F_FORCE_STREAM = 1, 2, 4, 8, 16
 F_NO_CHUNKING, F_FORCE_CHUNKING = 32, 64
 F_STREAM_CHAINS_2, F_STREAM_CHAINS_4, F_FORCE_EARLY, F_FORCE_LEAN, F_LEAN_CHAINS_4 = 128, 256, 512, 1024, 2048
+F_FORCE_PIECES = 4096
 
 
 class Opts(C.Structure):

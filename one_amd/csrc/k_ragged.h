@@ -407,8 +407,8 @@ k_ragged(DevDfa d, Batch io) {
   auto passedOver = [&](int c) -> bool { return !tOut[c] && tE[c] - tO[c] >= longFrom; };
   // the two top bits of a list entry's end say what it is (offsets stay far below 2^62)
   auto takeKind = [&](int c) {
-    tKind[c] = CLS ? 0u : uint32_t(tE[c] >> 62);
-    if (!CLS) tE[c] &= (1ull << 62) - 1;
+    tKind[c] = uint32_t(tE[c] >> 62);
+    tE[c] &= (1ull << 62) - 1;
   };
   auto lengthOf = [&](uint64_t o, uint64_t e) -> uint32_t {
     // Batch::stride doubles as "trailing delimiter bytes per line" for ragged lines
@@ -569,13 +569,14 @@ k_ragged(DevDfa d, Batch io) {
     }
     // a piece's lead-in block is behind it: what it arrived in (as a global state id) is the guess
     // of its entry state, and nothing seen on the way belongs to the piece
-    if (!CLS) {
+    auto globalOf = [&](int c) -> uint32_t {
+      return HOT ? (g[c] != kNoState ? g[c] : toGlobal(s[c])) : CLS ? toGlobal(s[c]) : s[c];
+    };
 #pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        if ((kind[c] & 1u) && done[c] == 0) {
-          ent[c] = HOT ? (g[c] != kNoState ? g[c] : toGlobal(s[c])) : s[c];
-          accS[c] = 0; endv[c] = 0; startv[c] = 0;
-        }
+    for (int c = 0; c < CH; ++c) {
+      if ((kind[c] & 1u) && done[c] == 0) {
+        ent[c] = globalOf(c);
+        accS[c] = 0; endv[c] = 0; startv[c] = 0;
       }
     }
 
@@ -634,8 +635,8 @@ k_ragged(DevDfa d, Batch io) {
         // a piece leaves its record where a line leaves its Outcome: the same three stores
         // (record: last accepting state | accepted << 31; end | exit state << 32 | entry guess
         // << 48, the states as global ids - at most 16 bits, the launcher sees to that; start)
-        const bool piece = !CLS && (kind[c] & 2u);
-        const uint32_t exitG = HOT ? (g[c] != kNoState ? g[c] : toGlobal(s[c])) : s[c];
+        const bool piece = (kind[c] & 2u) != 0;
+        const uint32_t exitG = globalOf(c);
         const int32_t rec = int32_t((endv[c] ? accS[c] : 0u) | (endv[c] ? 1u << 31 : 0u));
         const uint64_t recEnd = uint64_t(endv[c]) | (uint64_t(exitG & 0xffffu) << 32) |
                                 (uint64_t(ent[c] & 0xffffu) << 48);
@@ -988,11 +989,14 @@ k_ragged_outliers(const uint8_t *data, const uint64_t *offsets, uint64_t nMax, c
 constexpr int kFoldThreads = 256;
 constexpr int kFoldLines = kFoldThreads / 64;  // per workgroup and trip
 
-// (hot != 0: a REDGPU_TAB_HOT_ROWS DFA - a piece is walked again through its class table in
-// global memory, d.table as u16 rows of d.nClasses entries, byte -> class in d.equivLeader; a fused
-// table is staged to LDS instead)
+// (tabk: how a piece is walked again - kTabFused: the fused table, staged to LDS; kTabHot: a
+// REDGPU_TAB_HOT_ROWS DFA's class table in global memory, d.table as u16 rows of d.nClasses
+// entries, byte -> class in d.equivLeader; kTabCls / kTabClsBig: the class table k_ragged<cls>
+// stages, at d.table + d.clsOff = 256 bytes of 2 x class per byte, then rows of d.clsRowBytes
+// whose entries are the next state (kTabClsBig) or its row offset)
 __global__ void __launch_bounds__(kFoldThreads)
-k_ragged_pieces_fold(DevDfa d, Batch io, int acc, int wantStart, int hot) {
+k_ragged_pieces_fold(DevDfa d, Batch io, int acc, int wantStart, int tabk) {
+  const bool hot = tabk != kTabFused;  // (no LDS table)
   extern __shared__ __align__(16) uint8_t foldTab[];
   const uint32_t nHuge = io.outCtl[2];
   if (nHuge == 0) return;
@@ -1071,8 +1075,16 @@ k_ragged_pieces_fold(DevDfa d, Batch io, int acc, int wantStart, int hot) {
           for (uint64_t i = from; i < to; ++i) {
             const uint32_t was = s;
             const uint32_t byte = io.data[o + i];
-            s = hot ? uint32_t(cls[size_t(s) * d.nClasses + d.equivLeader[byte]])
-                    : uint32_t(foldTab[(s << 8) | byte]);
+            if (tabk == kTabFused) {
+              s = foldTab[(s << 8) | byte];
+            } else if (tabk == kTabHot) {
+              s = cls[size_t(s) * d.nClasses + d.equivLeader[byte]];
+            } else {
+              const uint8_t *cb = d.table + d.clsOff;
+              const uint32_t v = *reinterpret_cast<const uint16_t *>(
+                  cb + 256 + size_t(s) * d.clsRowBytes + cb[byte]);
+              s = tabk == kTabClsBig ? v : v / d.clsRowBytes;
+            }
             if (was == d.init && s != was) st = i;
             if (s >= d.firstAccept) { accepted = true; accState = s; en = i + 1; }
           }
@@ -1133,8 +1145,7 @@ hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
   const bool longFirst = factor && !cfg.noBucketing && b.n >= minLines;
   static const bool piecesOn = [] { const char *e = getenv("REDGPU_RAGGED_PIECES"); return !e || atoi(e) != 0; }();
   // (records keep states as 16-bit global ids)
-  const bool pieces = longFirst && piecesOn && d.forgetful && d.nStates <= 65535 &&
-                      (TABK == kTabFused || TABK == kTabHot);
+  const bool pieces = longFirst && piecesOn && (d.forgetful || cfg.forcePieces) && d.nStates <= 65535;
   const uint64_t perX = longFirst ? (b.n + factor - 1) / factor : 0;
   auto pad16 = [](size_t v) { return (v + 15) & ~size_t(15); };
   static const uint32_t hugeX = [] {
@@ -1198,7 +1209,7 @@ hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
   const uint64_t foldWant = (capH + kFoldLines - 1) / kFoldLines;
   const uint32_t foldBlocks = uint32_t(foldWant < 64 ? foldWant : 64);
   hipLaunchKernelGGL(k_ragged_pieces_fold, dim3(foldBlocks), dim3(kFoldThreads),
-                     TABK == kTabHot ? 0 : d.tableBytes, stream, d, rb, kAcc ? 1 : 0, kStart ? 1 : 0,
-                     TABK == kTabHot ? 1 : 0);
+                     TABK == kTabFused ? d.tableBytes : 0, stream, d, rb, kAcc ? 1 : 0,
+                     kStart ? 1 : 0, TABK);
   return hipGetLastError();
 }

@@ -97,6 +97,7 @@ struct LaunchCfg {
   int leanChains4 = 0;   // ... with four lines per lane (REDGPU_F_LEAN_CHAINS_4)
   int streamChains = 0;  // fixed-stride hot path: 0 = by batch size, 2 = k_stream.h always,
                          // 3 / 4 = k_stream4.hip always (REDGPU_F_STREAM_CHAINS_*; tests, tuning)
+  int forcePieces = 0;   // k_ragged: huge lines in pieces whatever the DFA (REDGPU_F_FORCE_PIECES)
 };
 
 // Launches the kernel for (verb, style, doLeader) on `stream`; returns hipSuccess or the

@@ -30,7 +30,7 @@ int checkStyle(int style) {
   return REDGPU_OK;
 }
 
-LaunchCfg cfgOf(const redgpu_dfa *dfa, uint32_t extraFlags = 0) {
+LaunchCfg cfgOfFlags(const redgpu_dfa *dfa, uint32_t extraFlags) {
   return LaunchCfg{dfa->numCUs, ((dfa->flags | extraFlags) & REDGPU_F_FORCE_GENERIC) ? 1 : 0,
                    (dfa->flags & REDGPU_F_NO_BUCKETING) ? 1 : 0,
                    (dfa->flags & REDGPU_F_FORCE_STREAM) ? 1 : 0,
@@ -41,6 +41,12 @@ LaunchCfg cfgOf(const redgpu_dfa *dfa, uint32_t extraFlags = 0) {
                    (dfa->flags & REDGPU_F_LEAN_CHAINS_4) ? 1 : 0,
                    (dfa->flags & REDGPU_F_STREAM_CHAINS_2) ? 2
                    : (dfa->flags & REDGPU_F_STREAM_CHAINS_4) ? 4 : 0};
+}
+
+LaunchCfg cfgOf(const redgpu_dfa *dfa, uint32_t extraFlags = 0) {
+  LaunchCfg cfg = cfgOfFlags(dfa, extraFlags);
+  cfg.forcePieces = (dfa->flags & REDGPU_F_FORCE_PIECES) ? 1 : 0;
+  return cfg;
 }
 
 int runDev(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint8_t *data,

@@ -80,7 +80,7 @@ class Executable:
                  force_global=False, force_hot=False, no_bucketing=False,
                  force_stream=False, no_chunking=False, force_chunking=False,
                  lds_table_max=0, stream_chains=0, force_early=False, force_lean=False,
-                 lean_chains=2):
+                 lean_chains=2, force_pieces=False):
         if serialized is None or len(serialized) == 0:
             raise RedExceptApi("serialized dfa string_view is empty")  # Executable.cpp:66
         o = _lib.Opts()
@@ -92,7 +92,7 @@ class Executable:
                                        force_stream=force_stream, no_chunking=no_chunking,
                                        force_chunking=force_chunking, stream_chains=stream_chains,
                                        force_early=force_early, force_lean=force_lean,
-                                       lean_chains=lean_chains)
+                                       lean_chains=lean_chains, force_pieces=force_pieces)
         self._h = C.c_void_p()
         blob = bytes(serialized)
         _check(_lib.lib().redgpu_dfa_create(blob, len(blob), C.byref(o), C.byref(self._h)))
@@ -100,7 +100,8 @@ class Executable:
     @staticmethod
     def _flags_of(force_generic=False, force_global=False, force_hot=False, no_bucketing=False,
                   force_stream=False, no_chunking=False, force_chunking=False, stream_chains=0,
-                  force_early=False, force_lean=False, lean_chains=2, **_ignored) -> int:
+                  force_early=False, force_lean=False, lean_chains=2, force_pieces=False,
+                  **_ignored) -> int:
         return ((_lib.F_FORCE_GENERIC if force_generic else 0) |
                 (_lib.F_FORCE_GLOBAL if force_global else 0) |
                 (_lib.F_FORCE_HOT if force_hot else 0) |
@@ -111,6 +112,7 @@ class Executable:
                 (_lib.F_FORCE_EARLY if force_early else 0) |
                 (_lib.F_FORCE_LEAN if force_lean else 0) |
                 (_lib.F_LEAN_CHAINS_4 if lean_chains == 4 else 0) |
+                (_lib.F_FORCE_PIECES if force_pieces else 0) |
                 (_lib.F_STREAM_CHAINS_2 if stream_chains == 2 else 0) |
                 (_lib.F_STREAM_CHAINS_4 if stream_chains == 4 else 0))
 

@@ -1445,7 +1445,7 @@ def test_ragged_long_lines_first(name):
 @pytest.mark.parametrize("name", ["uri", "newyork", "dotstar_err", "uri_v6", "uri_user", "syn256"])
 def test_ragged_huge_lines_in_pieces(name):
     """k_ragged's pieces: a line of >= 8 T bytes (T = max(512, 4 x mean), batches of >= 1024
-    lines, fused-u8 or hot-row table (uri_v6), a DFA flagged `forgetful`) is walked as ceil(len / T) pieces at once,
+    lines, a DFA flagged `forgetful`; fused-u8, hot-row (uri_v6) and class (uri_user) tables) is walked as ceil(len / T) pieces at once,
     each entered through a 64-byte lead-in from the initial state; k_ragged_pieces_fold chains the
     records and re-walks pieces whose guess was wrong.  The text is dense with matches, among them
     URLs of ~300 bytes, so that piece borders fall INSIDE matches (wrong guesses, accepts that
@@ -1501,6 +1501,43 @@ def test_ragged_huge_lines_in_pieces(name):
     er, es, ee = cpu.batch("match", 4, 0, data[keep], offsets=coffs, threads=4)
     r, s, e = one_amd.match_batch(exe, data, 4, 0, offsets=offsets, stride=1)
     assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee)
+
+
+@pytest.mark.parametrize("case", ["syn256", "rnd700x30", "rnd1500x40_big", "rnd3000_hot"])
+def test_ragged_pieces_forced_on_random_dfas(case):
+    """REDGPU_F_FORCE_PIECES on DFAs that do NOT forget their past (random transition tables):
+    nearly every piece's entry state is guessed wrong, so k_ragged_pieces_fold chains the records
+    serially and walks almost every piece again - through the fused table in LDS (syn256), the
+    class table in row-offset form (700 x 30) and in index form (1500 x 40, above 64 KB), and a
+    hot-row DFA's class table in global memory (3000 states).  Against the oracle and against the
+    same DFA without pieces."""
+    if case == "syn256":
+        blob = load_dfa("syn256")
+    else:
+        n_st, n_cls = {"rnd700x30": (700, 30), "rnd1500x40_big": (1500, 40),
+                       "rnd3000_hot": (3000, 64)}[case]
+        blob = random_dfa(n_st, n_cls, 93, accept_frac=0.15)
+    cpu = O.CpuOracle(blob)
+    hot = case.endswith("_hot")   # (a random table shows no locality: hot rows only when asked for)
+    exe = one_amd.Executable(blob, force_pieces=True, force_hot=hot)
+    plain = one_amd.Executable(blob, force_hot=hot)
+    kind = exe.info["table_kind"]
+    assert kind == {"syn256": 1, "rnd700x30": 3, "rnd1500x40_big": 3, "rnd3000_hot": 6}[case], exe.info
+    rng = np.random.default_rng(47)
+    n = 3000
+    lens = rng.integers(0, 80, n).astype(np.int64)
+    lens[rng.choice(n, 12, replace=False)] = rng.integers(5000, 30000, 12)
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    data = W.random_bytes(int(offsets[-1]), 49)
+    for si in (4, 5):
+        er, es, ee = cpu.batch("match", si, 0, data, offsets=offsets, threads=4)
+        for ex in (exe, plain):
+            r, s, e = one_amd.match_batch(ex, data, si, 0, offsets=offsets)
+            assert one_amd.last_kernel().startswith("k_ragged"), one_amd.last_kernel()
+            assert np.array_equal(r, er) and np.array_equal(s, es) and np.array_equal(e, ee), (case, si)
+        assert np.array_equal(one_amd.check_batch(exe, data, si, 0, offsets=offsets),
+                              cpu.batch("check", si, 0, data, offsets=offsets, threads=4)[0])
 
 
 def test_match_all_on_gpu():

@@ -23,6 +23,8 @@
 //   k_stream_multi.h  k_stream_multi: several batches in one launch (redgpu_*_batches_dev)
 //   k_ragged.h        k_ragged<MODE, TABK>: the walk over ragged lines, lanes refilled from a
 //                     workgroup cursor; the tail pad; k_generic's bucketing pre-pass
+//   k_ragged_long.h   k_ragged_outliers (the long lines of a batch: listed, walked first, huge ones as
+//                     pieces), k_ragged_pieces_fold (the pieces' records -> their lines' Outcomes)
 //   k_lists.h         k_collect, k_matchall, k_matchall_blocks (record lists per line)
 //   k_style_blocks.h  k_style_blocks: early-exit styles and odd strides over the block walk
 //   k_misc.h          k_advance, k_replace (+ scan), k_visits, k_walked

@@ -65,8 +65,8 @@ struct Batch {
   const uint64_t *outRec = nullptr; // [nOut][2] = the line's offsets[] pair
   const uint32_t *outLn = nullptr;  // [nOut] = its index
   const uint32_t *outCtl = nullptr; // [0] = nOut, [1] = the length from which a line is one
-  // ... and the lines of at least twice that length, cut into pieces that are walked at once
-  // (k_ragged.h "pieces"; fused-u8 and hot-row tables of DFAs that forget their past): records
+  // ... and the lines of at least 8 x that length, cut into pieces that are walked at once
+  // (k_ragged_long.h "pieces"; DFAs that forget their past): records
   // per piece, folded into the lines' Outcomes by k_ragged_pieces_fold; states as global ids
   int32_t *pieceRes = nullptr;      // [nPieces] last accepting state | accepted << 31
   uint64_t *pieceEnd = nullptr;     // [nPieces] end of that accept, from the piece's first walked

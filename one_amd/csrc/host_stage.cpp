@@ -233,8 +233,10 @@ void *HostStage::bounceTake(size_t bytes) {
 std::atomic<uint64_t> gRoute[4];  // transfers: caller-pinned, through the arena, registered, pageable
 
 void *HostStage::routeOf(const void *host, size_t bytes, int idx, bool direct) {
-  if (direct || isPinnedHost(host)) { ++gRoute[0]; return nullptr; }
   void *p = nullptr;
+  // (a small transfer of a small call is not worth asking the runtime what the memory is)
+  if (!direct && !callDirect_ && bytes <= 65536 && (p = bounceTake(bytes))) { ++gRoute[1]; return p; }
+  if (direct || isPinnedHost(host)) { ++gRoute[0]; return nullptr; }
   if (!callDirect_ && bytes <= kBounceMax && (p = bounceTake(bytes))) { ++gRoute[1]; return p; }
   if (pinForCall(host, bytes, idx)) { ++gRoute[2]; return nullptr; }
   if (bytes <= kBounceMax && (p = bounceTake(bytes))) { ++gRoute[1]; return p; }

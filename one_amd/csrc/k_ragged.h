@@ -572,11 +572,16 @@ k_ragged(DevDfa d, Batch io) {
     auto globalOf = [&](int c) -> uint32_t {
       return HOT ? (g[c] != kNoState ? g[c] : toGlobal(s[c])) : CLS ? toGlobal(s[c]) : s[c];
     };
+    // (pieces are rare: what concerns them sits behind one wave-uniform test per turn - done per
+    // lane on every turn it cost equal lines 4 % of their rate)
+    const bool anyPiece = __builtin_amdgcn_ballot_w64((kind[0] | kind[CH - 1]) != 0u) != 0;
+    if (anyPiece) {
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      if ((kind[c] & 1u) && done[c] == 0) {
-        ent[c] = globalOf(c);
-        accS[c] = 0; endv[c] = 0; startv[c] = 0;
+      for (int c = 0; c < CH; ++c) {
+        if ((kind[c] & 1u) && done[c] == 0) {
+          ent[c] = globalOf(c);
+          accS[c] = 0; endv[c] = 0; startv[c] = 0;
+        }
       }
     }
 
@@ -635,20 +640,25 @@ k_ragged(DevDfa d, Batch io) {
         // a piece leaves its record where a line leaves its Outcome: the same three stores
         // (record: last accepting state | accepted << 31; end | exit state << 32 | entry guess
         // << 48, the states as global ids - at most 16 bits, the launcher sees to that; start)
-        const bool piece = (kind[c] & 2u) != 0;
-        const uint32_t exitG = globalOf(c);
-        const int32_t rec = int32_t((endv[c] ? accS[c] : 0u) | (endv[c] ? 1u << 31 : 0u));
-        const uint64_t recEnd = uint64_t(endv[c]) | (uint64_t(exitG & 0xffffu) << 32) |
-                                (uint64_t(ent[c] & 0xffffu) << 48);
-        int32_t *rp = report ? (piece ? io.pieceRes : io.result) + at : reinterpret_cast<int32_t *>(dummy);
-        *rp = piece ? rec : rr;
-        uint64_t *endTo = piece ? io.pieceEnd : io.end;
+        int32_t v32 = rr;
+        uint64_t vEnd = rr ? uint64_t(en) : 0, vStart = rr ? uint64_t(st) : 0;
+        int32_t *resTo = io.result;
+        uint64_t *endTo = io.end, *startTo = io.start;
+        if (anyPiece && (kind[c] & 2u)) {
+          const uint32_t exitG = globalOf(c);
+          v32 = int32_t((endv[c] ? accS[c] : 0u) | (endv[c] ? 1u << 31 : 0u));
+          vEnd = uint64_t(endv[c]) | (uint64_t(exitG & 0xffffu) << 32) |
+                 (uint64_t(ent[c] & 0xffffu) << 48);
+          vStart = startv[c];
+          resTo = io.pieceRes; endTo = io.pieceEnd; startTo = io.pieceStart;
+        }
+        int32_t *rp = report ? resTo + at : reinterpret_cast<int32_t *>(dummy);
+        *rp = v32;
         uint64_t *ep = report && endTo ? endTo + at : reinterpret_cast<uint64_t *>(dummy);
-        *ep = piece ? recEnd : rr ? uint64_t(en) : 0;
+        *ep = vEnd;
         if (kStart) {
-          uint64_t *startTo = piece ? io.pieceStart : io.start;
           uint64_t *sp = report && startTo ? startTo + at : reinterpret_cast<uint64_t *>(dummy);
-          *sp = piece ? uint64_t(startv[c]) : rr ? uint64_t(st) : 0;
+          *sp = vStart;
         }
       }
       if (ends[c]) {
@@ -913,6 +923,7 @@ hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
     ob.capE = uint32_t(capE); ob.capH = uint32_t(capH); ob.capP = uint32_t(capP);
     e = hipMemsetAsync(ob.ctl, 0, 32, stream);
     if (e != hipSuccess) return e;
+    // (two workgroups per CU at most; 8 and 32 measured the same)
     const uint64_t want = (b.n + 4095) / 4096;
     const uint32_t nb = uint32_t(want < 2ull * uint64_t(cfg.numCUs) ? want : 2ull * uint64_t(cfg.numCUs));
     hipLaunchKernelGGL(k_ragged_outliers, dim3(nb), dim3(kOutlierThreads), 0, stream, b.data,

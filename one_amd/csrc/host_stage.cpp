@@ -30,6 +30,8 @@ struct ScratchEntry {
   void *ptr;
   size_t bytes;
   uint64_t stamp;
+  uint32_t *ctl = nullptr;  // two slots of 8 words (scratchCtlFor)
+  uint32_t ctlCalls = 0;
 };
 constexpr size_t kMaxPerThread = 48;
 std::atomic<size_t> gScratchCount{0};  // entries alive in all threads (redgpu_scratch_entries)
@@ -50,11 +52,23 @@ void freeEntry(ScratchEntry &en) {
   en.bytes = 0;
 }
 
+// (with the entry itself: eviction, a dropped stream, the thread leaving)
+void freeCtl(ScratchEntry &en) {
+  if (!en.ctl) return;
+  int cur = -1;
+  const bool sw = hipGetDevice(&cur) == hipSuccess && cur != en.dev &&
+                  hipSetDevice(en.dev) == hipSuccess;
+  (void)hipDeviceSynchronize();
+  (void)hipFree(en.ctl);
+  if (sw) (void)hipSetDevice(cur);
+  en.ctl = nullptr;
+}
+
 struct ThreadScratch {
   std::vector<ScratchEntry> v;
   uint64_t stamp = 0;
   void clear() {
-    for (auto &en : v) freeEntry(en);
+    for (auto &en : v) { freeEntry(en); freeCtl(en); }
     gScratchCount -= v.size();
     v.clear();
   }
@@ -83,6 +97,7 @@ hipError_t scratchFor(hipStream_t stream, size_t bytes, void **out) {
       for (size_t i = 1; i < ts.v.size(); ++i)
         if (ts.v[i].stamp < ts.v[lru].stamp) lru = i;
       freeEntry(ts.v[lru]);
+      freeCtl(ts.v[lru]);
       ts.v.erase(ts.v.begin() + long(lru));
       --gScratchCount;
     }
@@ -95,6 +110,7 @@ hipError_t scratchFor(hipStream_t stream, size_t bytes, void **out) {
   e = hipMalloc(&slot->ptr, want);
   if (e != hipSuccess) {
     slot->ptr = nullptr;
+    freeCtl(*slot);
     ts.v.erase(ts.v.begin() + (slot - ts.v.data()));
     --gScratchCount;
     return e;
@@ -105,11 +121,34 @@ hipError_t scratchFor(hipStream_t stream, size_t bytes, void **out) {
   return hipSuccess;
 }
 
+hipError_t scratchCtlFor(hipStream_t stream, uint32_t **out, uint32_t **next) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  ThreadScratch &ts = tlsScratch;
+  ScratchEntry *slot = nullptr;
+  for (auto &en : ts.v)
+    if (en.dev == dev && en.stream == stream) slot = &en;
+  if (!slot) return hipErrorInvalidValue;  // (scratchFor first: it makes the entry)
+  if (!slot->ctl) {
+    e = hipMalloc(reinterpret_cast<void **>(&slot->ctl), 64);
+    if (e != hipSuccess) { slot->ctl = nullptr; return e; }
+    e = hipMemset(slot->ctl, 0, 64);  // (once per entry, synchronous)
+    if (e != hipSuccess) return e;
+    slot->ctlCalls = 0;
+  }
+  const uint32_t k = slot->ctlCalls++ & 1u;
+  *out = slot->ctl + 8 * k;
+  *next = slot->ctl + 8 * (k ^ 1u);
+  return hipSuccess;
+}
+
 void scratchDrop(int device, hipStream_t stream) {
   ThreadScratch &ts = tlsScratch;
   for (size_t i = 0; i < ts.v.size();) {
     if (ts.v[i].dev == device && ts.v[i].stream == stream) {
       freeEntry(ts.v[i]);
+      freeCtl(ts.v[i]);
       ts.v.erase(ts.v.begin() + long(i));
       --gScratchCount;
     } else {

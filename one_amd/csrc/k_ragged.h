@@ -881,7 +881,7 @@ hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
   Batch rb = b;
   // lines are handed out in input order, the long ones of a large batch first
   // (REDGPU_F_NO_BUCKETING: plain input order), the huge ones of a forgetful DFA in pieces.
-  // Scratch: [pad 256][ctl 32][outLn u32[capE]][outRec u64[2 capE]][hugeLn, hugeFirst u32[capH]]
+  // Scratch: [pad 256][32 unused][outLn u32[capE]][outRec u64[2 capE]][hugeLn, hugeFirst u32[capH]]
   // [pieceRes i32[capP]][pieceEnd, pieceStart u64[capP]], every part 16-byte aligned.
   const uint32_t factor = raggedLongFactor();
   static const uint64_t minLines = [] {
@@ -915,14 +915,16 @@ hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
   rb.outLn = reinterpret_cast<const uint32_t *>(pad);
   if (longFirst) {
     OutlierBufs ob;
-    ob.ctl = reinterpret_cast<uint32_t *>(pad + 256);
+    // (the control words are not in the scratch buffer, which every launch family of the thread
+    // and stream overwrites, but beside it: this call's slot arrives zeroed - by the pre-pass of
+    // the call before - and the sequence needs no memset in front)
+    e = scratchCtlFor(stream, &ob.ctl, &ob.ctlNext);
+    if (e != hipSuccess) return e;
     ob.outLn = reinterpret_cast<uint32_t *>(pad + offLn);
     ob.outRec = reinterpret_cast<uint64_t *>(pad + offRec);
     ob.hugeLn = reinterpret_cast<uint32_t *>(pad + offHuge);
     ob.hugeFirst = reinterpret_cast<uint32_t *>(pad + offHuge + pad16(capH * 4));
     ob.capE = uint32_t(capE); ob.capH = uint32_t(capH); ob.capP = uint32_t(capP);
-    e = hipMemsetAsync(ob.ctl, 0, 32, stream);
-    if (e != hipSuccess) return e;
     // (two workgroups per CU at most; 8 and 32 measured the same)
     const uint64_t want = (b.n + 4095) / 4096;
     const uint32_t nb = uint32_t(want < 2ull * uint64_t(cfg.numCUs) ? want : 2ull * uint64_t(cfg.numCUs));

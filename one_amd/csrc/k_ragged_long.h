@@ -35,6 +35,7 @@ constexpr uint64_t kEntryLead = 1ull << 62;
 
 struct OutlierBufs {
   uint32_t *ctl;     // [0] entries, [1] T, [2] lines in pieces, [3] pieces, [4] C (8 words)
+  uint32_t *ctlNext; // the control words of the NEXT call on this thread and stream: zeroed here
   uint32_t *outLn;   // [capE] line index, or the piece's index
   uint64_t *outRec;  // [capE][2] first byte walked, end (+ trailing bytes to drop) | flags
   uint32_t *hugeLn, *hugeFirst;  // [capH]
@@ -57,6 +58,7 @@ k_ragged_outliers(const uint8_t *data, const uint64_t *offsets, uint64_t nMax, c
   if (T >= 0xffffffffull) T = 0xffffffffull;  // "no line is long" to k_ragged
   const uint64_t C = T;
   if (blockIdx.x == 0 && threadIdx.x == 0) { ob.ctl[1] = uint32_t(T); ob.ctl[4] = uint32_t(C); }
+  if (blockIdx.x == 0 && threadIdx.x < 8) ob.ctlNext[threadIdx.x] = 0;
   if (T == 0xffffffffull) return;
   if (threadIdx.x < 3) { cnt[threadIdx.x] = 0; fill[threadIdx.x] = 0; }
   __syncthreads();
@@ -253,8 +255,8 @@ k_ragged_pieces_fold(DevDfa d, Batch io, int acc, int wantStart, int tabk) {
   }
 }
 
-// the smallest batch whose long lines are listed.  The list costs a small batch 5-6 us (1024 to
-// 16384 lines of 32-256 B: 34 -> 40 us per launch) and is what keeps ONE huge line from holding
+// the smallest batch whose long lines are listed.  The list costs a small batch ~4 us (4096
+// lines of 32-256 B: 34.6 -> 38.2 us per launch) and is what keeps ONE huge line from holding
 // it for milliseconds (the same batches with a 1 MB line: 67.5 ms -> 0.17-0.36 ms;
 // scripts/lab/run_small.sh).
 constexpr uint64_t kLongFirstMinLines = 1024;

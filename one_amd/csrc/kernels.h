@@ -182,6 +182,11 @@ hipError_t launchStream4(int mode, const DevDfa &dfa, const Batch &b, const Laun
 // other thread may be handed it - bounded, freed at thread exit / redgpu_thread_release(),
 // entries of a library-owned stream dropped with the stream.  scratchEntries: all threads'.
 hipError_t scratchFor(hipStream_t stream, size_t bytes, void **out);
+// The same entry's CONTROL words: two slots of 8 x uint32 that only k_ragged's launch sequence
+// touches (the scratch buffer itself is shared with every other launch family of the thread and
+// stream).  *out = the slot of this call, zero on arrival; *next = the other one, which the
+// call's first kernel zeroes for the call after it - so no launch sequence starts with a memset.
+hipError_t scratchCtlFor(hipStream_t stream, uint32_t **out, uint32_t **next);
 void scratchDrop(int device, hipStream_t stream);
 void scratchReleaseThread();
 size_t scratchEntries();

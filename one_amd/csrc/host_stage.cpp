@@ -133,7 +133,11 @@ hipError_t scratchCtlFor(hipStream_t stream, uint32_t **out, uint32_t **next) {
   if (!slot->ctl) {
     e = hipMalloc(reinterpret_cast<void **>(&slot->ctl), 64);
     if (e != hipSuccess) { slot->ctl = nullptr; return e; }
-    e = hipMemset(slot->ctl, 0, 64);  // (once per entry, synchronous)
+    // once per entry, ON THE ENTRY'S STREAM: a hipMemset goes to the null stream, which the
+    // caller's non-blocking stream does not wait for - the pre-pass ran ahead of it once in a
+    // few hundred first calls, the memset then wiped what it had written (the threshold, so
+    // every line was "passed over"), and one worker of the 8-thread test got stale answers
+    e = hipMemsetAsync(slot->ctl, 0, 64, stream);
     if (e != hipSuccess) return e;
     slot->ctlCalls = 0;
   }
@@ -271,37 +275,72 @@ void *HostStage::bounceTake(size_t bytes) {
 // otherwise through `*slice` of the arena
 std::atomic<uint64_t> gRoute[4];  // transfers: caller-pinned, through the arena, registered, pageable
 
-void *HostStage::routeOf(const void *host, size_t bytes, int idx, bool direct) {
-  void *p = nullptr;
-  // (a small transfer of a small call is not worth asking the runtime what the memory is)
-  if (!direct && !callDirect_ && bytes <= 65536 && (p = bounceTake(bytes))) { ++gRoute[1]; return p; }
-  if (direct || isPinnedHost(host)) { ++gRoute[0]; return nullptr; }
-  if (!callDirect_ && bytes <= kBounceMax && (p = bounceTake(bytes))) { ++gRoute[1]; return p; }
-  if (pinForCall(host, bytes, idx)) { ++gRoute[2]; return nullptr; }
-  if (bytes <= kBounceMax && (p = bounceTake(bytes))) { ++gRoute[1]; return p; }
-  ++gRoute[3];
-  return nullptr;  // pageable, as a last resort
-}
-
 void hostRouteCounts(uint64_t out[4]) {
   for (int i = 0; i < 4; ++i) out[i] = gRoute[i].load();
 }
 
-hipError_t HostStage::copyIn(void *dDst, const void *hSrc, size_t bytes, int idx, bool direct) {
+// One transfer of caller memory, either direction (toDevice: dev <- host).
+//  * memory the caller pinned (`direct`, or the runtime says so for both ends of the range): as it is;
+//  * a small call (beginCall) or a small transfer: through the arena;
+//  * otherwise the WHOLE PAGES inside the range are registered for the call and copied as they
+//    are, and the partial pages at its two ends go through the arena.  Registration is by page:
+//    two buffers that share a page - numpy's result / start / end arrays sit back to back in the
+//    heap - registered one after the other and released one after the other left a page
+//    unmapped under a copy that still needed it (the "Memory access fault ... on address
+//    0x5a95..." of round 3, before and after the explicit registration).  Registering only what
+//    a buffer owns alone cannot collide;
+//  * what the runtime refuses to register goes through the arena piece by piece.  Nothing is
+//    ever handed over pageable.
+hipError_t HostStage::move(void *dev, void *host, size_t bytes, int idx, bool direct, bool toDevice) {
   if (bytes == 0) return hipSuccess;
-  void *p = routeOf(hSrc, bytes, idx, direct);
-  if (!p) return hipMemcpyAsync(dDst, hSrc, bytes, hipMemcpyHostToDevice, streams[idx]);
-  memcpy(p, hSrc, bytes);
-  return hipMemcpyAsync(dDst, p, bytes, hipMemcpyHostToDevice, streams[idx]);
+  hipStream_t s = streams[idx];
+  auto plain = [&](void *d, void *h, size_t n) {
+    return toDevice ? hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s)
+                    : hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s);
+  };
+  // through the arena, in pieces the arena can hold (bounceTake waits and starts over when full)
+  auto bounced = [&](uint8_t *d, uint8_t *h, size_t n) -> hipError_t {
+    constexpr size_t kPiece = size_t(4) << 20;
+    for (size_t at = 0; at < n; at += kPiece) {
+      const size_t m = n - at < kPiece ? n - at : kPiece;
+      void *p = bounceTake(m);
+      if (!p) return hipErrorOutOfMemory;
+      hipError_t e;
+      if (toDevice) {
+        memcpy(p, h + at, m);
+        e = hipMemcpyAsync(d + at, p, m, hipMemcpyHostToDevice, s);
+      } else {
+        e = hipMemcpyAsync(p, d + at, m, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) pending_.push_back(Pending{h + at, p, m, idx});
+      }
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  };
+  uint8_t *d8 = static_cast<uint8_t *>(dev), *h8 = static_cast<uint8_t *>(host);
+  if (!direct && !callDirect_ && bytes <= kBounceMax) { ++gRoute[1]; return bounced(d8, h8, bytes); }
+  if (direct || (isPinnedHost(h8) && isPinnedHost(h8 + bytes - 1))) { ++gRoute[0]; return plain(dev, host, bytes); }
+  constexpr uintptr_t kPage = 4096;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(h8);
+  const uintptr_t lo = (a + kPage - 1) & ~(kPage - 1), hi = (a + bytes) & ~(kPage - 1);
+  if (hi > lo && hi - lo >= 16 * kPage && pinForCall(reinterpret_cast<void *>(lo), hi - lo, idx)) {
+    ++gRoute[2];
+    const size_t head = lo - a, tail = a + bytes - hi;
+    hipError_t e = plain(d8 + head, reinterpret_cast<void *>(lo), hi - lo);
+    if (e == hipSuccess && head) e = bounced(d8, h8, head);
+    if (e == hipSuccess && tail) e = bounced(d8 + (bytes - tail), h8 + (bytes - tail), tail);
+    return e;
+  }
+  ++gRoute[1];
+  return bounced(d8, h8, bytes);
+}
+
+hipError_t HostStage::copyIn(void *dDst, const void *hSrc, size_t bytes, int idx, bool direct) {
+  return move(dDst, const_cast<void *>(hSrc), bytes, idx, direct, true);
 }
 
 hipError_t HostStage::copyOut(void *hDst, const void *dSrc, size_t bytes, int idx, bool direct) {
-  if (bytes == 0) return hipSuccess;
-  void *p = routeOf(hDst, bytes, idx, direct);
-  if (!p) return hipMemcpyAsync(hDst, dSrc, bytes, hipMemcpyDeviceToHost, streams[idx]);
-  hipError_t e = hipMemcpyAsync(p, dSrc, bytes, hipMemcpyDeviceToHost, streams[idx]);
-  if (e == hipSuccess) pending_.push_back(Pending{hDst, p, bytes, idx});
-  return e;
+  return move(const_cast<void *>(dSrc), hDst, bytes, idx, direct, false);
 }
 
 hipError_t HostStage::textPipe() {

@@ -50,11 +50,10 @@ class HostStage {
   // an intermittent "Memory access fault" at a host heap address in the test suite, whose numpy
   // buffers come and go).  Larger transfers and memory the caller pinned go direct.
   // A throughput call's pageable buffers are REGISTERED for the duration of the call instead
-  // (hipHostRegister now, hipHostUnregister behind the stream's next drain): the copies then run
-  // on memory the runtime knows as pinned, and its own on-the-fly path is never taken.  (Leaving
-  // the large calls on that path was tried first: the fault came back within five suite runs, in
-  // an 18 MB call.)  A range the runtime refuses to register falls back to the arena, and only
-  // what fits neither way is handed over pageable.
+  // (hipHostRegister now, hipHostUnregister behind the stream's next drain) - the whole pages
+  // inside each buffer only, its partial end pages go through the arena (HostStage::move has the
+  // why) - so the runtime's own on-the-fly path is never taken.  A range the runtime refuses to
+  // register goes through the arena in pieces.
   // copyOut()'s bytes are in the caller's buffer after syncStream(idx) / sync().
   static constexpr size_t kBounceMax = size_t(16) << 20;
   static constexpr size_t kDirectFrom = size_t(8) << 20;
@@ -71,7 +70,7 @@ class HostStage {
 
  private:
   void *bounceTake(size_t bytes);
-  void *routeOf(const void *host, size_t bytes, int idx, bool direct);
+  hipError_t move(void *dev, void *host, size_t bytes, int idx, bool direct, bool toDevice);
   bool pinForCall(const void *p, size_t bytes, int idx);
   struct TempPin {
     void *p;

@@ -266,13 +266,10 @@ int runHost(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint
 
   // pinned caller memory makes the copies truly asynchronous (only worth its price when there
   // is something to overlap)
-  const bool pinNow = multi && !callerPinned;
-  // the caller's memory is pinned (by the caller, or for this call just below: several chunks)
-  // and copied as it is; otherwise HostStage::copyIn / copyOut choose per transfer (a small call's
-  // pageable memory through the thread's pinned arena, a large one's registered for the call)
+  // the caller's memory is pinned and copied as it is; otherwise HostStage::copyIn / copyOut
+  // choose per transfer (a small call's pageable memory through the thread's pinned arena, a
+  // large one's whole pages registered for the call - per chunk when there are several)
   const bool direct = callerPinned;
-  ScopedPin pinIn(data, total, pinNow), pinRes(result, n * 4, pinNow),
-      pinStart(start, start ? n * 8 : 0, pinNow), pinEnd(end, end ? n * 8 : 0, pinNow);
 
   if (offsets) {
     STAGE_TRY(st->copyIn(dOff, offsets, (n + 1) * 8, 0, direct), "copy offsets");

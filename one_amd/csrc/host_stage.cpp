@@ -343,34 +343,12 @@ hipError_t HostStage::copyOut(void *hDst, const void *dSrc, size_t bytes, int id
   return move(const_cast<void *>(dSrc), hDst, bytes, idx, direct, false);
 }
 
-hipError_t HostStage::textPipe() {
-  if (textWords) return hipSuccess;
-  hipError_t e = hipEventCreateWithFlags(&textFork, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&textJoin, hipEventDisableTiming);
-  for (int k = 0; k < kTextParts && e == hipSuccess; ++k)
-    e = hipEventCreateWithFlags(&partEv[k], hipEventDisableTiming);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&textWords), (2 * kTextParts + 2) * 8);
-  if (e != hipSuccess) textWords = nullptr;
-  return e;
-}
-
 void HostStage::release() {
   if (device < 0) return;
   int prev = -1;
   const bool sw = hipGetDevice(&prev) == hipSuccess && prev != device &&
                   hipSetDevice(device) == hipSuccess;
   (void)sync();
-  if (textJoined || textWords) (void)hipDeviceSynchronize();  // (the caller's stream may still read the words)
-  if (textWords) (void)hipFree(textWords);
-  textWords = nullptr;
-  if (textFork) (void)hipEventDestroy(textFork);
-  if (textJoin) (void)hipEventDestroy(textJoin);
-  textFork = textJoin = nullptr;
-  textJoined = false;
-  for (hipEvent_t &ev : partEv) {
-    if (ev) (void)hipEventDestroy(ev);
-    ev = nullptr;
-  }
   for (Buf &b : bufs_) {
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;

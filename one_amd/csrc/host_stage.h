@@ -24,13 +24,6 @@ class HostStage {
   int device = -1;
   hipStream_t streams[2] = {nullptr, nullptr};
   hipEvent_t ready = nullptr;  // "the shared uploads (offsets, replacement) have landed"
-  // redgpu_*_text_dev's pipeline (made on first use by textPipe()): streams[1] splits part k + 1
-  // of the text while the caller's stream matches part k
-  static constexpr int kTextParts = 8;
-  hipEvent_t textFork = nullptr, textJoin = nullptr, partEv[kTextParts] = {};
-  bool textJoined = false;      // textJoin has been recorded (the next call's splits wait for it)
-  uint64_t *textWords = nullptr;  // device: [k] = lines in front of part k, [kTextParts + 1 + k] = lines of part k
-  hipError_t textPipe();
 
   // grow-only device buffer `slot` of at least `bytes` (+16: 16-byte loads of a last line never
   // leave the allocation).  Growing waits for this thread's own streams, then frees and allocates.

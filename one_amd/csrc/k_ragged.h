@@ -194,28 +194,11 @@ __device__ __forceinline__ void raggedWalk16Cls(const uint4 (&piece)[2], uint32_
 #undef RGC_WORD
 }
 
-// lines of the batch: Batch::n, or what the device-side count says if that is fewer; with a
-// device-side first line (baseDev) the lines from there on, room for n in all
-__device__ __forceinline__ uint64_t raggedLineCount(uint64_t n, const uint64_t *nDev,
-                                                    uint64_t base = 0) {
-  const uint64_t room = base < n ? n - base : 0;
-  if (!nDev) return room;
+// lines of the batch: Batch::n, or what the device-side count says if that is fewer
+__device__ __forceinline__ uint64_t raggedLineCount(uint64_t n, const uint64_t *nDev) {
+  if (!nDev) return n;
   const uint64_t have = *nDev;
-  return have < room ? have : room;
-}
-__device__ __forceinline__ uint64_t raggedBase(uint64_t n, const uint64_t *baseDev) {
-  if (!baseDev) return 0;
-  const uint64_t b = *baseDev;
-  return b < n ? b : n;
-}
-// the batch's arrays moved to its first line; returns its line count
-__device__ __forceinline__ uint64_t raggedShift(Batch &io) {
-  const uint64_t base = raggedBase(io.n, io.baseDev);
-  io.offsets += base;
-  io.result += base;
-  if (io.start) io.start += base;
-  if (io.end) io.end += base;
-  return raggedLineCount(io.n, io.nDev, base);
+  return have < n ? have : n;
 }
 
 // a wave-uniform 64-bit value the compiler must keep in SGPRs (it feeds "s" asm operands)
@@ -353,7 +336,7 @@ k_ragged(DevDfa d, Batch io) {
   asm volatile("" : : "v"(tab) : "memory");  // the table is read from inline asm: see k_stream.h
   __syncthreads();
 
-  const uint64_t nLines = raggedShift(io);
+  const uint64_t nLines = raggedLineCount(io.n, io.nDev);
   const uint64_t total = io.offsets[nLines];
   const uint64_t padStart = total >= 128 ? total - 128 : 0;  // pad[] = data[padStart, total) + 0s
   const int32_t initResult = IDXD ? (d.init >= d.firstAccept ? d.result[d.init] : 0)
@@ -846,9 +829,8 @@ inline hipError_t raggedScratch(hipStream_t stream, size_t bytes, void **out) {
 // pad[0..192) = data[padStart, total) followed by zeros (see the header comment)
 __global__ void __launch_bounds__(192)
 k_tail_pad(const uint8_t *data, const uint64_t *offsets, uint64_t nMax, uint8_t *pad,
-           const uint64_t *nDev = nullptr, const uint64_t *baseDev = nullptr) {
-  const uint64_t base = raggedBase(nMax, baseDev);
-  const uint64_t total = offsets[base + raggedLineCount(nMax, nDev, base)];
+           const uint64_t *nDev = nullptr) {
+  const uint64_t total = offsets[raggedLineCount(nMax, nDev)];
   const uint64_t padStart = total >= 128 ? total - 128 : 0;
   const uint64_t i = padStart + threadIdx.x;
   pad[threadIdx.x] = i < total ? data[i] : uint8_t(0);
@@ -947,8 +929,7 @@ hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
     const uint64_t want = (b.n + 4095) / 4096;
     const uint32_t nb = uint32_t(want < 2ull * uint64_t(cfg.numCUs) ? want : 2ull * uint64_t(cfg.numCUs));
     hipLaunchKernelGGL(k_ragged_outliers, dim3(nb), dim3(kOutlierThreads), 0, stream, b.data,
-                       b.offsets, b.n, b.nDev, b.baseDev, factor, uint32_t(b.stride),
-                       pieces ? hugeX : 0u, pad, ob);
+                       b.offsets, b.n, b.nDev, factor, uint32_t(b.stride), pieces ? hugeX : 0u, pad, ob);
     rb.outCtl = ob.ctl;
     rb.outLn = ob.outLn;
     rb.outRec = ob.outRec;
@@ -961,7 +942,7 @@ hipError_t launchRaggedT(const DevDfa &d, const Batch &b, const LaunchCfg &cfg,
     }
   } else {
     hipLaunchKernelGGL(k_tail_pad, dim3(1), dim3(192), 0, stream, b.data, b.offsets, b.n, pad,
-                       b.nDev, b.baseDev);
+                       b.nDev);
   }
   e = hipGetLastError();
   if (e != hipSuccess) return e;

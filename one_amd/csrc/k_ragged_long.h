@@ -44,19 +44,15 @@ struct OutlierBufs {
 
 __global__ void __launch_bounds__(kOutlierThreads)
 k_ragged_outliers(const uint8_t *data, const uint64_t *offsets, uint64_t nMax, const uint64_t *nDev,
-                  const uint64_t *baseDev, uint32_t factor, uint32_t trim, uint32_t hugeX,
-                  uint8_t *pad, OutlierBufs ob) {
+                  uint32_t factor, uint32_t trim, uint32_t hugeX, uint8_t *pad, OutlierBufs ob) {
   __shared__ uint32_t cnt[3], base[3], fill[3];  // entries, huge lines, pieces
-  const uint64_t firstLine = raggedBase(nMax, baseDev);  // (line indices below count from there)
-  offsets += firstLine;
-  const uint64_t n = raggedLineCount(nMax, nDev, firstLine);
+  const uint64_t n = raggedLineCount(nMax, nDev);
   const uint64_t total = offsets[n];
   if (blockIdx.x == 0 && threadIdx.x < 192) {
     const uint64_t i = (total >= 128 ? total - 128 : 0) + threadIdx.x;
     pad[threadIdx.x] = i < total ? data[i] : uint8_t(0);
   }
-  const uint64_t bytes = total - offsets[0];  // (the lines' lengths sum to this)
-  uint64_t T = n ? (bytes + n - 1) / n * factor : 0xffffffffull;
+  uint64_t T = n ? (total + n - 1) / n * factor : 0xffffffffull;
   if (T < kOutlierMinBytes) T = kOutlierMinBytes;
   T = (T + 63) & ~63ull;  // pieces are whole blocks
   if (T >= 0xffffffffull) T = 0xffffffffull;  // "no line is long" to k_ragged
@@ -153,7 +149,6 @@ k_ragged_pieces_fold(DevDfa d, Batch io, int acc, int wantStart, int tabk) {
   extern __shared__ __align__(16) uint8_t foldTab[];
   const uint32_t nHuge = io.outCtl[2];
   if (nHuge == 0) return;
-  (void)raggedShift(io);
   const uint64_t C = io.outCtl[4];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   bool staged = false;

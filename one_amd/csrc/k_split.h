@@ -123,18 +123,13 @@ k_split_count(const uint8_t *data, uint64_t len, uint32_t delim, uint64_t nChunk
 // (The first form gave thread t the 16 contiguous counts of 256 MiB's 16384 chunks and had
 // thread 0 walk the 1024 partial sums: 39 us, a third of the whole split; dependent loads and
 // stores per thread still cost 28.)
-// (carryIn / partCount: the text is split in PARTS, one after the other - redgpu_*_text_dev's
-// pipeline: the lines in front of this part come in through *carryIn, the running total goes out
-// through *nLines, this part's own count through *partCount)
 __global__ void __launch_bounds__(1024)
 k_split_scan(const uint32_t *counts, uint64_t nChunks, uint64_t *bases, uint64_t *nLines,
-             uint64_t *offsets, uint64_t cap, const uint64_t *carryIn, uint64_t *partCount,
-             uint64_t *nLinesToo) {
+             uint64_t *offsets, uint64_t cap) {
   constexpr int kRows = 8;
   __shared__ uint32_t waveTot[2][kRows][16];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint64_t before0 = carryIn ? *carryIn : 0;
-  uint64_t carry = before0;
+  uint64_t carry = 0;
   int buf = 0;
   for (uint64_t tile = 0; tile < nChunks; tile += uint64_t(kRows) * 1024, buf ^= 1) {
     uint32_t c[kRows], incl[kRows];
@@ -174,9 +169,7 @@ k_split_scan(const uint32_t *counts, uint64_t nChunks, uint64_t *bases, uint64_t
   }
   if (threadIdx.x == 0) {
     *nLines = carry;
-    if (nLinesToo) *nLinesToo = carry;
-    if (partCount) *partCount = carry - before0;
-    if (!carryIn) offsets[0] = 0;
+    offsets[0] = 0;
   }
 }
 
@@ -185,10 +178,9 @@ k_split_scan(const uint32_t *counts, uint64_t nChunks, uint64_t *bases, uint64_t
 // scans of all pieces, one barrier, then every lane places its pieces' lines (the first form ran
 // the pieces one after the other with three barriers each: 33 us per 256 MiB, now 27, for a pass
 // that moves 47 MB).
-// (byteBase: where this part starts in the whole text)
 __global__ void __launch_bounds__(kSplitThreads)
 k_split_scatter(const uint16_t *allMasks, uint64_t nChunks, const uint64_t *bases, uint64_t *offsets,
-                uint64_t cap, uint64_t byteBase) {
+                uint64_t cap) {
   constexpr int kWaves = kSplitThreads / 64;
   constexpr int kP = kSplitGroup * kSplitPieces;
   __shared__ uint32_t waveTot[kP][kWaves];
@@ -229,7 +221,7 @@ k_split_scatter(const uint16_t *allMasks, uint64_t nChunks, const uint64_t *base
     }
     before += tot;
     uint64_t at = first + mine + (incl[p] - c[p]);  // index of this lane's first delimiter
-    const uint64_t pos = byteBase + (chunk0 + p / kSplitPieces) * kSplitChunk +
+    const uint64_t pos = (chunk0 + p / kSplitPieces) * kSplitChunk +
                          uint64_t((p % kSplitPieces) * kSplitThreads + threadIdx.x) * 16;
     uint32_t mm = m[p];
     while (mm) {

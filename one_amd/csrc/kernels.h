@@ -78,10 +78,6 @@ struct Batch {
   // count is still on the device - min(*nDev, n) lines, n = what the arrays have room for
   // (redgpu_*_text_dev: the count comes from the line split queued just before)
   const uint64_t *nDev = nullptr;
-  // ... and so is the index of the batch's first line: offsets / result / start / end are the
-  // whole arrays and this batch is their lines [*baseDev, *baseDev + min(*nDev, n - *baseDev))
-  // (one part of a text whose splitting is still going on: redgpu_*_text_dev's pipeline)
-  const uint64_t *baseDev = nullptr;
   uint32_t spread = 1;            // k_generic only: one line per `spread` lanes (table in L2)
   uint32_t ignoreAcceptUpTo = 0;  // k_stream / k_stream_multi, check<..., true> over a forced leader:
                                   // accepts at positions <= this (the post-leader state's own
@@ -151,21 +147,11 @@ hipError_t launchReplace(const DevDfa &dfa, const Batch &b, int style, int doLea
 // k-th delimiter, for k < cap; *nLines = delimiters found.  counts: uint32[splitChunks(len)],
 // bases: uint64[splitChunks(len)], masks: splitMaskBytes(len) bytes (16-byte aligned) - scratch,
 // all device memory.
-constexpr uint64_t kSplitChunkBytes = 16384;  // bytes per workgroup of the split passes (k_split.h)
 uint64_t splitChunks(uint64_t len);
 uint64_t splitMaskBytes(uint64_t len);
 hipError_t launchSplitLines(const uint8_t *data, uint64_t len, uint8_t delim, uint64_t *offsets,
                             uint64_t cap, uint64_t *nLines, uint32_t *counts, uint64_t *bases,
                             uint16_t *masks, hipStream_t stream);
-// The same for ONE PART of the text, data[byteBase, byteBase + len) with byteBase a multiple of
-// 16 KiB: the lines that end in front of it come in through *linesBefore (nullptr: none, and
-// offsets[0] = 0 is written), the running total goes out through *linesAfter (and
-// *linesAfterToo), this part's own count through *partCount; positions and line indices are the
-// whole text's.  Scratch sized for the part.
-hipError_t launchSplitPart(const uint8_t *data, uint64_t byteBase, uint64_t len, uint8_t delim,
-                           uint64_t *offsets, uint64_t cap, const uint64_t *linesBefore,
-                           uint64_t *linesAfter, uint64_t *partCount, uint64_t *linesAfterToo,
-                           uint32_t *counts, uint64_t *bases, uint16_t *masks, hipStream_t stream);
 
 // bench.py's read-bandwidth calibration: one streaming pass over `bytes` (16-byte aligned).
 hipError_t launchDiagRead(const void *data, uint64_t bytes, uint32_t *sink, int numCUs,
@@ -229,7 +215,5 @@ hipError_t launchAdvanceStream(const DevDfa &dfa, const Batch &b, uint32_t *stat
 
 // True when the specialised fixed-stride kernels can run this DFA at all.
 bool fastPathEligible(const DevDfa &dfa);
-// would launchBatch hand ragged lines of this (verb, style, doLeader) to the k_ragged family?
-bool raggedFamilyTakes(const DevDfa &dfa, int verb, int style, int doLeader, const LaunchCfg &cfg);
 
 } // namespace redgpu

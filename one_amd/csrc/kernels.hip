@@ -557,30 +557,21 @@ hipError_t launchReplace(const DevDfa &d, const Batch &b, int style, int doLeade
 
 uint64_t splitChunks(uint64_t len) { return (len + kSplitChunk - 1) / kSplitChunk; }
 
-static_assert(kSplitChunkBytes == kSplitChunk, "kernels.h and k_split.h disagree");
 uint64_t splitMaskBytes(uint64_t len) { return splitChunks(len) * (kSplitChunk / 8); }
 
 hipError_t launchSplitLines(const uint8_t *data, uint64_t len, uint8_t delim, uint64_t *offsets,
                             uint64_t cap, uint64_t *nLines, uint32_t *counts, uint64_t *bases,
                             uint16_t *masks, hipStream_t stream) {
-  return launchSplitPart(data, 0, len, delim, offsets, cap, nullptr, nLines, nullptr, nullptr,
-                         counts, bases, masks, stream);
-}
-
-hipError_t launchSplitPart(const uint8_t *data, uint64_t byteBase, uint64_t len, uint8_t delim,
-                           uint64_t *offsets, uint64_t cap, const uint64_t *linesBefore,
-                           uint64_t *linesAfter, uint64_t *partCount, uint64_t *linesAfterToo,
-                           uint32_t *counts, uint64_t *bases, uint16_t *masks, hipStream_t stream) {
   const uint64_t nChunks = splitChunks(len);
   const uint32_t groups = uint32_t((nChunks + kSplitGroup - 1) / kSplitGroup);
   if (nChunks)
-    hipLaunchKernelGGL(k_split_count, dim3(groups), dim3(kSplitThreads), 0, stream, data + byteBase,
-                       len, uint32_t(delim), nChunks, counts, masks);
-  hipLaunchKernelGGL(k_split_scan, dim3(1), dim3(1024), 0, stream, counts, nChunks, bases,
-                     linesAfter, offsets, cap, linesBefore, partCount, linesAfterToo);
+    hipLaunchKernelGGL(k_split_count, dim3(groups), dim3(kSplitThreads), 0, stream, data, len,
+                       uint32_t(delim), nChunks, counts, masks);
+  hipLaunchKernelGGL(k_split_scan, dim3(1), dim3(1024), 0, stream, counts, nChunks, bases, nLines,
+                     offsets, cap);
   if (nChunks)
     hipLaunchKernelGGL(k_split_scatter, dim3(groups), dim3(kSplitThreads), 0, stream, masks,
-                       nChunks, bases, offsets, cap, byteBase);
+                       nChunks, bases, offsets, cap);
   return hipGetLastError();
 }
 
@@ -683,18 +674,6 @@ static void normalizeVerbStyle(const DevDfa &d, const LaunchCfg &cfg, bool lead,
   if (verb == kCheck && !lead && d.uniformResult && !d.earlyDeath && !cfg.forceGeneric &&
       (style == kStyInstant || style == kStyFirst || style == kStyTangent))
     style = kStyLast;
-}
-
-// would launchBatch hand ragged lines of this (verb, style, doLeader) to the k_ragged family?
-// (launchRaggedFamily's conditions; redgpu_*_text_dev's pipeline asks before it starts)
-bool raggedFamilyTakes(const DevDfa &d, int verb, int style, int doLeader, const LaunchCfg &cfg) {
-  const bool lead = doLeader && d.leaderLen > 0;
-  normalizeVerbStyle(d, cfg, lead, verb, style);
-  const bool dying = d.earlyDeath && !cfg.forceStream;
-  if (cfg.forceGeneric || dying || lead) return false;
-  if (!((verb == kCheck || verb == kMatch) && (style == kStyLast || style == kStyFull))) return false;
-  return (fastPathEligible(d) && d.tableBytes <= kStreamTabBytes && d.nStates <= 256) ||
-         hotStreamEligible(d) || clsStreamEligible(d);
 }
 
 hipError_t launchBatches(const DevDfa &d, const Batch *bs, uint32_t nb, int verb, int style,

@@ -792,66 +792,6 @@ int redgpu_split_lines_dev(const redgpu_dfa *dfa, const uint8_t *data, uint64_t 
   return REDGPU_OK;
 }
 
-// bytes per part of redgpu_*_text_dev's pipeline (REDGPU_TEXT_PART_MB; 0 = one part, no pipeline)
-static uint64_t textPartBytes() {
-  static const uint64_t v = [] {
-    const char *e = getenv("REDGPU_TEXT_PART_MB");
-    const long mb = e ? atol(e) : 0;
-    return uint64_t(mb < 0 ? 0 : mb > 4096 ? 4096 : mb) << 20;
-  }();
-  return v;
-}
-
-static int textPipeline(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint8_t *data,
-                        uint64_t len, uint8_t delim, uint64_t *offsets, uint64_t cap,
-                        uint64_t *n_lines, int32_t *result, uint64_t *start, uint64_t *end,
-                        hipStream_t s, uint64_t part, const LaunchCfg &cfg) {
-  HostStage *st = nullptr;
-  if (int rc = stageOf(dfa, &st)) return rc;
-  HIP_TRY(st->textPipe(), "text pipeline (events)");
-  constexpr int K = HostStage::kTextParts;
-  uint64_t parts = (len + part - 1) / part;
-  if (parts > uint64_t(K)) {  // at most K parts: larger ones
-    part = ((len + K - 1) / K + kSplitChunkBytes - 1) / kSplitChunkBytes * kSplitChunkBytes;
-    parts = (len + part - 1) / part;
-  }
-  if (cap > len) cap = len;  // a buffer holds no more lines than bytes
-  hipStream_t side = st->streams[1];
-  uint64_t *words = st->textWords;
-  // the side stream starts behind what the caller's stream holds now (the text may still be on its
-  // way) and behind the last call's matches (they read the words this one overwrites)
-  HIP_TRY(hipEventRecord(st->textFork, s), "hipEventRecord");
-  HIP_TRY(hipStreamWaitEvent(side, st->textFork, 0), "hipStreamWaitEvent");
-  if (st->textJoined) HIP_TRY(hipStreamWaitEvent(side, st->textJoin, 0), "hipStreamWaitEvent");
-  const uint64_t partChunks = splitChunks(part);
-  const size_t countBytes = (size_t(partChunks) * 4 + 15) & ~size_t(15);
-  const size_t headBytes = countBytes + size_t(partChunks) * 8 + 16;
-  void *scratch = nullptr;
-  HIP_TRY(scratchFor(side, headBytes + splitMaskBytes(part) + 16, &scratch), "hipMalloc scratch");
-  uint32_t *counts = static_cast<uint32_t *>(scratch);
-  uint64_t *bases = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(scratch) + countBytes);
-  uint16_t *masks = reinterpret_cast<uint16_t *>(static_cast<uint8_t *>(scratch) + headBytes);
-  const char *name = "";
-  for (uint64_t k = 0; k < parts; ++k) {
-    const uint64_t from = k * part, plen = from + part < len ? part : len - from;
-    hipError_t e = launchSplitPart(data, from, plen, delim, offsets, cap, k ? words + k : nullptr,
-                                   words + k + 1, words + K + 1 + k,
-                                   k + 1 == parts ? n_lines : nullptr, counts, bases, masks, side);
-    if (e != hipSuccess) return failHip(e, "kernel launch");
-    HIP_TRY(hipEventRecord(st->partEv[k], side), "hipEventRecord");
-    HIP_TRY(hipStreamWaitEvent(s, st->partEv[k], 0), "hipStreamWaitEvent");
-    Batch b{data, offsets, 1, cap, result, start, end};
-    b.nDev = words + K + 1 + k;
-    b.baseDev = k ? words + k : nullptr;
-    e = launchBatch(dfa->im->dev, b, verb, style, doLeader ? 1 : 0, cfg, s, &name);
-    if (e != hipSuccess) return failHip(e, "kernel launch");
-  }
-  HIP_TRY(hipEventRecord(st->textJoin, s), "hipEventRecord");
-  st->textJoined = true;
-  tlsKernel = name;
-  return REDGPU_OK;
-}
-
 // raw text -> lines -> check / match, one call, everything on `stream`
 static int textDev(const redgpu_dfa *dfa, int verb, int style, int doLeader, const uint8_t *data,
                    uint64_t len, uint8_t delim, uint64_t *offsets, uint64_t cap, uint64_t *n_lines,
@@ -859,20 +799,6 @@ static int textDev(const redgpu_dfa *dfa, int verb, int style, int doLeader, con
   if (!dfa) return fail(REDGPU_EAPI, "null dfa handle");
   if (int rc = checkStyle(style)) return rc;
   if (cap && !result) return fail(REDGPU_EAPI, "null result buffer");
-  // A large text goes in PARTS: the thread's side stream splits part k + 1 while the caller's stream
-  // matches part k (the split reads the text at HBM speed, the walk is bound by its table
-  // lookups: they run side by side).  For the DFAs the k_ragged family takes - it reads a part's
-  // first line and line count on the device (Batch::baseDev / nDev).
-  if (dfa && dfa->im->device >= 0 && offsets && n_lines && (len == 0 || data) && cap) {
-    const uint64_t part = textPartBytes();
-    DeviceScope scope(dfa->im->device);
-    if (scope.err != hipSuccess) return failHip(scope.err, "hipSetDevice");
-    const LaunchCfg cfg = cfgOf(dfa);
-    if (part && len >= 2 * part && (reinterpret_cast<uintptr_t>(data) & 15u) == 0 &&
-        raggedFamilyTakes(dfa->im->dev, verb, style, doLeader ? 1 : 0, cfg))
-      return textPipeline(dfa, verb, style, doLeader, data, len, delim, offsets, cap, n_lines, result,
-                          start, end, static_cast<hipStream_t>(stream), part, cfg);
-  }
   if (int rc = redgpu_split_lines_dev(dfa, data, len, delim, offsets, cap, n_lines, stream)) return rc;
   if (cap > len) cap = len;  // a buffer holds no more lines than bytes
   if (cap == 0) return REDGPU_OK;

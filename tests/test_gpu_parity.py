@@ -944,21 +944,6 @@ def test_match_text_one_call(name):
         assert one_amd.last_kernel().startswith("k_ragged"), one_amd.last_kernel()
 
 
-def test_text_pipeline_in_parts():
-    """REDGPU_TEXT_PART_MB (opt-in: it measures slower): the text split in parts on the
-    thread's side stream while the caller's stream matches the part before - Batch::baseDev, the
-    split's carry between parts.  The library reads the variable once per process, so the check
-    runs in one of its own (tests/text_pipeline_check.py)."""
-    import os
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, REDGPU_TEXT_PART_MB="1")
-    out = subprocess.run([sys.executable, os.path.join(here, "text_pipeline_check.py")], env=env,
-                         capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "text pipeline ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
-
-
 @pytest.mark.parametrize("name", ["syn256", "uri"])
 def test_ragged_length_bucketing_vs_oracle(name):
     """k_ragged behind its length-bucketing pass (>= 16384 lines): skewed line lengths - many

@@ -347,11 +347,24 @@ int uploadImage(SharedImage *im) {
     return failHip(e, "hipMalloc result");
   if ((e = hipMalloc(&im->dEquivLeader, 1024 + 64)) != hipSuccess) return failHip(e, "hipMalloc equiv");
   if ((e = hipMemset(im->dTable, 0, tabBytes + 16)) != hipSuccess) return failHip(e, "hipMemset");
-  if ((e = hipMemcpy(im->dTable, img.table.data(), img.table.size(), hipMemcpyHostToDevice)) !=
-      hipSuccess)
+  // The table and the result array are heap memory of this process (std::vector): uploaded
+  // THROUGH A PINNED BUFFER of the library's own, never as they are - above ~1 MiB the runtime
+  // would pin the vector's pages on the fly, by address, and a GPU fault at a heap address was
+  // seen three times exactly here, under the 2 MiB table of SYN-4K, when the heap around it
+  // had just been registered and released for a host-buffer call.
+  auto upload = [](void *dst, const void *src, size_t bytes) -> hipError_t {
+    if (bytes == 0) return hipSuccess;
+    void *pin = nullptr;
+    hipError_t e2 = hipHostMalloc(&pin, bytes, hipHostMallocDefault);
+    if (e2 != hipSuccess) return e2;
+    std::memcpy(pin, src, bytes);
+    e2 = hipMemcpy(dst, pin, bytes, hipMemcpyHostToDevice);
+    (void)hipHostFree(pin);
+    return e2;
+  };
+  if ((e = upload(im->dTable, img.table.data(), img.table.size())) != hipSuccess)
     return failHip(e, "upload table");
-  if ((e = hipMemcpy(im->dResult, img.result.data(), img.nStates * sizeof(int32_t),
-                     hipMemcpyHostToDevice)) != hipSuccess)
+  if ((e = upload(im->dResult, img.result.data(), img.nStates * sizeof(int32_t))) != hipSuccess)
     return failHip(e, "upload result");
   if ((e = hipMemcpy(im->dEquivLeader, eqLead, 1024, hipMemcpyHostToDevice)) != hipSuccess)
     return failHip(e, "upload equiv");

@@ -521,6 +521,12 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
+    # the synchronize above may have put this core to sleep: a core that wakes into the timed
+    # region issued the one launch of configs[1] in 113 us instead of 25 (one run in fifteen).
+    # 300 us of spinning on the clock - no GPU work, nothing of a step - and it is awake.
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 300e-6:
+        pass
 
     ev0.record()           # (asynchronous: the idle GPU stamps it at once; its host cost is not a step's)
     t0 = time.perf_counter()
